@@ -1,0 +1,324 @@
+// rzk_core.h — lane-level arithmetic, register/LDS geometry and the wave NTT of the MI355X backend.
+//
+// One 64-lane wavefront transforms one residue polynomial of N = 2^LOGN coefficients
+// (LOGN = 9, 10, 11; E = N/64 coefficients per lane).  The transform is a negacyclic
+// Cooley-Tukey NTT (forward, natural -> bit-reversed order) / Gentleman-Sande inverse over an
+// auxiliary 30-bit prime p = 1 (mod 8192), with 32-bit Montgomery multiplication (R = 2^32, one
+// v_mad_u64_u32 + v_mul_lo_u32 + v_mad_u64_u32) and Harvey lazy reduction (values in [0,4p)
+// forward, [0,2p) inverse).  It runs in three register phases separated by two transpositions
+// through a wave-private LDS buffer:
+//
+//   phase 1  lane holds a[e*64 + lane]               stages 0 .. LE-1       (twiddles wave-uniform)
+//   phase 2  lane holds a[hi*64 + r*2^(6-LE) + lo]   stages LE .. 2LE-1     (twiddles per lane)
+//   phase 3  lane holds a[lane*E + c]                stages 2LE .. LOGN-1   (twiddles per lane)
+//
+// Every function here is written over an explicit (lane, register array, LDS pointer) so that the
+// very same code is compiled (a) by hipcc into the gfx950 kernels and (b) by g++ into the CPU
+// lane emulator under tests/emul/, which replays the 64 lanes phase by phase and lets the index
+// arithmetic be checked bit-for-bit against the oracle without a GPU.  The emulator is test
+// infrastructure; the product library contains only the HIP build.
+//
+// The reference has no counterpart for any of this: its ring multiply lives in the third-party
+// crate poly-ring-xnp1 (Cargo.toml:18) and is called at src/mat.rs:110, src/mat.rs:176 and
+// src/prove/linear.rs:94.  Because Q = 3515337053 = 5 (mod 8) has no 2N-th root of unity
+// (SURVEY.md §0 fact 3), products are computed exactly over Z via CRT on up to three auxiliary
+// primes and then reduced to the centred representative mod Q.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define RZK_HD __host__ __device__ __forceinline__
+#else
+#define RZK_HD inline
+#endif
+
+namespace rzk {
+
+constexpr int kMaxPrimes = 3;
+constexpr int kTableLog = 12;            // twiddle tables cover N <= 4096
+constexpr int kTableLen = 1 << kTableLog;
+
+// The three auxiliary primes: largest primes below 2^30 with p = 1 (mod 8192).
+// p < 2^30 keeps lazy values (< 4p) inside 32 bits; p > (Q-1)/4 lets a centred input x be lifted
+// to the lazy range with a single add (x + 2p in [0,4p)).
+constexpr uint32_t kPrimes[kMaxPrimes] = {1073692673u, 1073668097u, 1073651713u};
+constexpr uint32_t kPrimeGenerators[kMaxPrimes] = {3u, 3u, 10u};
+
+struct PrimeConsts {   // per auxiliary prime
+  uint32_t p;
+  uint32_t twop;
+  uint32_t npinv;      // -p^{-1} mod 2^32
+  uint32_t r2;         // 2^64 mod p   (mont(x, r2) = x * R : conversion into Montgomery form)
+  uint32_t ninv_r;     // N^{-1} * R   mod p : mont(x, ninv_r)  = x * N^{-1}
+  uint32_t ninv_r2;    // N^{-1} * R^2 mod p : mont(x, ninv_r2) = x * N^{-1} * R
+  uint32_t pad0, pad1;
+};
+
+// ---- Montgomery arithmetic, R = 2^32 -------------------------------------------------------------
+// x < 2^32, w < p < 2^30.  Returns x*w*R^{-1} mod p as a lazy value in [0, 2p).
+RZK_HD uint32_t mont_lazy(uint32_t x, uint32_t w, uint32_t p, uint32_t npinv) {
+  uint64_t t = (uint64_t)x * w;
+  uint32_t m = (uint32_t)t * npinv;
+  uint64_t u = (uint64_t)m * p + t;   // low 32 bits are zero; < 2^63
+  return (uint32_t)(u >> 32);
+}
+// unsigned conditional subtract: v in [0, 2m) -> [0, m)
+RZK_HD uint32_t csub(uint32_t v, uint32_t m) {
+  uint32_t d = v - m;
+  return d < v ? d : v;   // d wraps above v exactly when v < m
+}
+
+// Cooley-Tukey butterfly, Harvey lazy: X, Y in [0,4p) -> [0,4p).  w in Montgomery form.
+RZK_HD void bfly_fwd(uint32_t& X, uint32_t& Y, uint32_t w, const PrimeConsts& pc) {
+  uint32_t x = csub(X, pc.twop);
+  uint32_t v = mont_lazy(Y, w, pc.p, pc.npinv);
+  X = x + v;
+  Y = x - v + pc.twop;
+}
+// Gentleman-Sande butterfly, lazy: X, Y in [0,2p) -> [0,2p).  w in Montgomery form.
+RZK_HD void bfly_inv(uint32_t& X, uint32_t& Y, uint32_t w, const PrimeConsts& pc) {
+  uint32_t s = X + Y;
+  uint32_t d = X - Y + pc.twop;
+  X = csub(s, pc.twop);
+  Y = mont_lazy(d, w, pc.p, pc.npinv);
+}
+
+// ---- geometry ------------------------------------------------------------------------------------
+template <int LOGN>
+struct Geo {
+  static_assert(LOGN >= 9 && LOGN <= 11, "one wavefront per polynomial supports N = 512, 1024, 2048");
+  static constexpr int N = 1 << LOGN;
+  static constexpr int LE = LOGN - 6;      // local bits per phase
+  static constexpr int E = 1 << LE;        // coefficients per lane
+  static constexpr int R3 = LOGN - 2 * LE; // stages left for phase 3 (= 6 - LE)
+  static constexpr int LOSH = 6 - LE;      // low lane bits of phase 2
+  // LDS word address of coefficient j: one pad word per 32 keeps all three access patterns
+  // (phase-1 rows, phase-2 strided, phase-3 blocked) bank-conflict free for ds_*_b32
+  // (N = 1024, 2048) or 2-way (N = 512); see tools/lds_conflicts.py.
+  static constexpr int LDS_WORDS = N + N / 32;
+  RZK_HD static int lds_addr(int j) { return j + (j >> 5); }
+  // phase-2 lane split.  N <= 1024: hi = lane & (E-1), lo = lane >> LE ; N = 2048: hi = lane >> 1.
+  static constexpr bool P2_HI_LOW = (LOGN <= 10);
+  RZK_HD static int p2_hi(int lane) { return P2_HI_LOW ? (lane & (E - 1)) : (lane >> LOSH); }
+  RZK_HD static int p2_lo(int lane) { return P2_HI_LOW ? (lane >> LE) : (lane & ((1 << LOSH) - 1)); }
+  // coefficient index held by (lane, reg) in each phase
+  RZK_HD static int j_p1(int lane, int e) { return e * 64 + lane; }
+  RZK_HD static int j_p2(int lane, int r) { return p2_hi(lane) * 64 + (r << LOSH) + p2_lo(lane); }
+  RZK_HD static int j_p3(int lane, int c) { return lane * E + c; }
+  // "RZK NTT layout": word offset, inside one N-word residue polynomial in global memory, of the
+  // phase-3 register c of `lane`; groups of 4 registers form one 16-byte coalesced access.
+  RZK_HD static int mem_p3(int lane, int c) { return (c >> 2) * 256 + lane * 4 + (c & 3); }
+};
+
+// ---- LDS transpositions -----------------------------------------------------------------------------
+template <int LOGN>
+RZK_HD void lds_put_p1(const uint32_t* x, int lane, uint32_t* lds) {
+  using G = Geo<LOGN>;
+#pragma unroll
+  for (int e = 0; e < G::E; ++e) lds[G::lds_addr(G::j_p1(lane, e))] = x[e];
+}
+template <int LOGN>
+RZK_HD void lds_get_p1(uint32_t* x, int lane, const uint32_t* lds) {
+  using G = Geo<LOGN>;
+#pragma unroll
+  for (int e = 0; e < G::E; ++e) x[e] = lds[G::lds_addr(G::j_p1(lane, e))];
+}
+template <int LOGN>
+RZK_HD void lds_put_p2(const uint32_t* x, int lane, uint32_t* lds) {
+  using G = Geo<LOGN>;
+  const int base = G::p2_hi(lane) * 64 + G::p2_lo(lane);
+#pragma unroll
+  for (int r = 0; r < G::E; ++r) lds[G::lds_addr(base + (r << G::LOSH))] = x[r];
+}
+template <int LOGN>
+RZK_HD void lds_get_p2(uint32_t* x, int lane, const uint32_t* lds) {
+  using G = Geo<LOGN>;
+  const int base = G::p2_hi(lane) * 64 + G::p2_lo(lane);
+#pragma unroll
+  for (int r = 0; r < G::E; ++r) x[r] = lds[G::lds_addr(base + (r << G::LOSH))];
+}
+template <int LOGN>
+RZK_HD void lds_put_p3(const uint32_t* x, int lane, uint32_t* lds) {
+  using G = Geo<LOGN>;
+#pragma unroll
+  for (int c = 0; c < G::E; ++c) lds[G::lds_addr(G::j_p3(lane, c))] = x[c];
+}
+template <int LOGN>
+RZK_HD void lds_get_p3(uint32_t* x, int lane, const uint32_t* lds) {
+  using G = Geo<LOGN>;
+#pragma unroll
+  for (int c = 0; c < G::E; ++c) x[c] = lds[G::lds_addr(G::j_p3(lane, c))];
+}
+
+// ---- forward transform, register phases ----------------------------------------------------------------
+// tw: Montgomery-form table, tw[m + i] = psi^{bitrev(m+i)} * R mod p (first N entries used).
+template <int LOGN>
+RZK_HD void fwd_phase1(uint32_t* x, const uint32_t* tw, const PrimeConsts& pc) {
+  using G = Geo<LOGN>;
+#pragma unroll
+  for (int s = 0; s < G::LE; ++s) {
+    const int half = G::E >> (s + 1);
+#pragma unroll
+    for (int e = 0; e < G::E; ++e) {
+      if (e & half) continue;
+      const uint32_t w = tw[(1 << s) + (e >> (G::LE - s))];   // wave-uniform
+      bfly_fwd(x[e], x[e + half], w, pc);
+    }
+  }
+}
+template <int LOGN>
+RZK_HD void fwd_phase2(uint32_t* x, int lane, const uint32_t* tw, const PrimeConsts& pc) {
+  using G = Geo<LOGN>;
+  const int hi = G::p2_hi(lane);
+#pragma unroll
+  for (int sp = 0; sp < G::LE; ++sp) {
+    const int half = G::E >> (sp + 1);
+    const uint32_t* twl = tw + (1 << (G::LE + sp)) + (hi << sp);   // 2^sp contiguous entries
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) {
+      if (r & half) continue;
+      bfly_fwd(x[r], x[r + half], twl[r >> (G::LE - sp)], pc);
+    }
+  }
+}
+template <int LOGN>
+RZK_HD void fwd_phase3(uint32_t* x, int lane, const uint32_t* tw, const PrimeConsts& pc) {
+  using G = Geo<LOGN>;
+#pragma unroll
+  for (int sq = 0; sq < G::R3; ++sq) {
+    const int sh = G::R3 - sq;            // idx = 2^s + (j >> sh)
+    const int half = 1 << (sh - 1);
+    const uint32_t* twl = tw + (1 << (2 * G::LE + sq)) + lane * (G::E >> sh);
+#pragma unroll
+    for (int c = 0; c < G::E; ++c) {
+      if (c & half) continue;
+      bfly_fwd(x[c], x[c + half], twl[c >> sh], pc);
+    }
+  }
+}
+
+// ---- inverse transform, register phases (mirror image; tw = psi^{-bitrev} * R) -------------------------------
+template <int LOGN>
+RZK_HD void inv_phase3(uint32_t* x, int lane, const uint32_t* tw, const PrimeConsts& pc) {
+  using G = Geo<LOGN>;
+#pragma unroll
+  for (int sq = G::R3 - 1; sq >= 0; --sq) {
+    const int sh = G::R3 - sq;
+    const int half = 1 << (sh - 1);
+    const uint32_t* twl = tw + (1 << (2 * G::LE + sq)) + lane * (G::E >> sh);
+#pragma unroll
+    for (int c = 0; c < G::E; ++c) {
+      if (c & half) continue;
+      bfly_inv(x[c], x[c + half], twl[c >> sh], pc);
+    }
+  }
+}
+template <int LOGN>
+RZK_HD void inv_phase2(uint32_t* x, int lane, const uint32_t* tw, const PrimeConsts& pc) {
+  using G = Geo<LOGN>;
+  const int hi = G::p2_hi(lane);
+#pragma unroll
+  for (int sp = G::LE - 1; sp >= 0; --sp) {
+    const int half = G::E >> (sp + 1);
+    const uint32_t* twl = tw + (1 << (G::LE + sp)) + (hi << sp);
+#pragma unroll
+    for (int r = 0; r < G::E; ++r) {
+      if (r & half) continue;
+      bfly_inv(x[r], x[r + half], twl[r >> (G::LE - sp)], pc);
+    }
+  }
+}
+template <int LOGN>
+RZK_HD void inv_phase1(uint32_t* x, const uint32_t* tw, const PrimeConsts& pc) {
+  using G = Geo<LOGN>;
+#pragma unroll
+  for (int s = G::LE - 1; s >= 0; --s) {
+    const int half = G::E >> (s + 1);
+#pragma unroll
+    for (int e = 0; e < G::E; ++e) {
+      if (e & half) continue;
+      const uint32_t w = tw[(1 << s) + (e >> (G::LE - s))];
+      bfly_inv(x[e], x[e + half], w, pc);
+    }
+  }
+}
+
+// ---- lifting centred coefficients into a prime field, pointwise products -----------------------------------
+// centred coefficient (|v| <= (Q-1)/2 < 2p) -> lazy residue in [0,4p)
+RZK_HD uint32_t lift(int32_t v, const PrimeConsts& pc) { return (uint32_t)v + pc.twop; }
+
+// acc in [0,2p), x < 2^32, k in Montgomery form (< p): acc +/- x*k  -> [0,2p)
+RZK_HD uint32_t mac_add(uint32_t acc, uint32_t x, uint32_t k, const PrimeConsts& pc) {
+  return csub(acc + mont_lazy(x, k, pc.p, pc.npinv), pc.twop);
+}
+RZK_HD uint32_t mac_sub(uint32_t acc, uint32_t x, uint32_t k, const PrimeConsts& pc) {
+  return csub(acc + pc.twop - mont_lazy(x, k, pc.p, pc.npinv), pc.twop);
+}
+
+// ---- CRT reconstruction and reduction to the centred representative mod q ------------------------------------
+struct CrtConsts {
+  uint32_t q, qinv;        // ring modulus (odd, < 2^32) and q^{-1} mod 2^32
+  uint32_t qhalf;          // (q-1)/2
+  uint32_t inv01_r;        // p0^{-1} mod p1, Montgomery form mod p1
+  uint32_t p0_mod_p2_r;    // p0 mod p2, Montgomery form mod p2
+  uint32_t inv012_r;       // (p0*p1)^{-1} mod p2, Montgomery form mod p2
+  uint32_t c1;             // p0      * 2^32 mod q
+  uint32_t c2;             // p0 * p1 * 2^32 mod q
+  uint32_t pmodq[4];       // [np] = (p0*..*p_{np-1}) mod q
+  uint32_t half1;          // (p0+1)/2
+  uint32_t half3_d2;       // (P3+1)/2 = half3_lo + half3_d2 * (p0*p1)
+  uint64_t half2;          // (p0*p1+1)/2
+  uint64_t half3_lo;
+};
+
+// a*c*2^{-32} mod q as a signed value in (-q, q);  a, c < 2^32
+RZK_HD int64_t montq(uint32_t a, uint32_t c, const CrtConsts& C) {
+  uint64_t t = (uint64_t)a * c;
+  uint32_t m = (uint32_t)t * C.qinv;
+  uint32_t h = (uint32_t)(((uint64_t)m * C.q) >> 32);
+  return (int64_t)(uint32_t)(t >> 32) - (int64_t)h;
+}
+// s -> centred representative, for |s| < (2*ROUNDS - 1) * q / 2 ... conservatively |s| < ROUNDS*q
+template <int ROUNDS>
+RZK_HD int64_t center_rounds(int64_t s, const CrtConsts& C) {
+  const int64_t q = C.q, h = C.qhalf;
+#pragma unroll
+  for (int i = 0; i < ROUNDS; ++i) {
+    s = s > h ? s - q : s;
+    s = s < -h ? s + q : s;
+  }
+  return s;
+}
+// Residues r[i] in [0,2p_i) (lazy, as left by the inverse transform) of an integer X with
+// |X| < P_np/2  ->  centred representative of X mod q, as a signed value in [-(q-1)/2, (q-1)/2].
+RZK_HD int64_t crt_center(uint32_t r0, uint32_t r1, uint32_t r2, int np, const PrimeConsts* pc,
+                          const CrtConsts& C) {
+  const uint32_t d0 = csub(r0, pc[0].p);
+  int64_t s = d0;
+  bool neg;
+  if (np == 1) {
+    neg = d0 >= C.half1;
+  } else {
+    // d1 = (r1 - d0) * p0^{-1} mod p1
+    const uint32_t t1 = r1 + pc[1].twop - d0;   // r1 < 2p1, d0 < p0 < 2p1  ->  in (0, 4p1)
+    const uint32_t d1 = csub(mont_lazy(t1, C.inv01_r, pc[1].p, pc[1].npinv), pc[1].p);
+    const uint64_t lo = (uint64_t)d1 * pc[0].p + d0;   // X mod p0p1
+    s += montq(d1, C.c1, C);
+    if (np == 2) {
+      neg = lo >= C.half2;
+    } else {
+      // d2 = (r2 - (d0 + d1*p0)) * (p0p1)^{-1} mod p2
+      const uint32_t m1 = mont_lazy(d1, C.p0_mod_p2_r, pc[2].p, pc[2].npinv);   // d1*p0 mod p2, [0,2p2)
+      const uint32_t low2 = csub(csub(d0, pc[2].p) + m1, pc[2].twop);           // (d0 + d1 p0) mod p2, [0,2p2)
+      const uint32_t t2 = r2 + pc[2].twop - low2;                               // (0, 4p2)
+      const uint32_t d2 = csub(mont_lazy(t2, C.inv012_r, pc[2].p, pc[2].npinv), pc[2].p);
+      s += montq(d2, C.c2, C);
+      neg = (d2 > C.half3_d2) || (d2 == C.half3_d2 && lo >= C.half3_lo);
+    }
+  }
+  if (neg) s -= C.pmodq[np];
+  return center_rounds<3>(s, C);
+}
+
+}  // namespace rzk

@@ -1,0 +1,141 @@
+// CPU lane emulator for ring_zk_amd/csrc/rzk_core.h (TEST INFRASTRUCTURE — not part of the product).
+// Replays the 64 lanes of one wavefront phase by phase, with the wave-private LDS buffer as a plain
+// array, so the register/LDS index arithmetic and the modular arithmetic of the HIP kernels can be
+// checked bit-for-bit against the oracle in a container without a GPU.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../ring_zk_amd/csrc/rzk_core.h"
+#include "../../ring_zk_amd/csrc/rzk_tables.h"
+
+using namespace rzk;
+
+namespace {
+
+struct Tables {
+  std::vector<uint32_t> fwd[kMaxPrimes], inv[kMaxPrimes];
+  Tables() {
+    for (int i = 0; i < kMaxPrimes; ++i) host::make_twiddles(i, fwd[i], inv[i]);
+  }
+};
+const Tables& tables() {
+  static Tables t;
+  return t;
+}
+
+template <int LOGN>
+struct Wave {
+  using G = Geo<LOGN>;
+  uint32_t x[64][G::E];
+  uint32_t lds[G::LDS_WORDS];
+
+  void forward(const uint32_t* tw, const PrimeConsts& pc) {   // x in phase-1 layout -> phase-3 layout
+    for (int l = 0; l < 64; ++l) { fwd_phase1<LOGN>(x[l], tw, pc); lds_put_p1<LOGN>(x[l], l, lds); }
+    for (int l = 0; l < 64; ++l) { lds_get_p2<LOGN>(x[l], l, lds); fwd_phase2<LOGN>(x[l], l, tw, pc); }
+    for (int l = 0; l < 64; ++l) lds_put_p2<LOGN>(x[l], l, lds);
+    for (int l = 0; l < 64; ++l) { lds_get_p3<LOGN>(x[l], l, lds); fwd_phase3<LOGN>(x[l], l, tw, pc); }
+  }
+  void inverse(const uint32_t* tw, const PrimeConsts& pc) {   // phase-3 layout -> phase-1 layout
+    for (int l = 0; l < 64; ++l) { inv_phase3<LOGN>(x[l], l, tw, pc); lds_put_p3<LOGN>(x[l], l, lds); }
+    for (int l = 0; l < 64; ++l) { lds_get_p2<LOGN>(x[l], l, lds); inv_phase2<LOGN>(x[l], l, tw, pc); }
+    for (int l = 0; l < 64; ++l) lds_put_p2<LOGN>(x[l], l, lds);
+    for (int l = 0; l < 64; ++l) { lds_get_p1<LOGN>(x[l], l, lds); inv_phase1<LOGN>(x[l], tw, pc); }
+  }
+};
+
+template <int LOGN>
+int ntt_fwd(int pi, const uint32_t* in, uint32_t* out_std, uint32_t* out_mem) {
+  using G = Geo<LOGN>;
+  PrimeConsts pc = host::make_prime_consts(pi, G::N);
+  static Wave<LOGN> w;
+  for (int l = 0; l < 64; ++l)
+    for (int e = 0; e < G::E; ++e) w.x[l][e] = in[G::j_p1(l, e)];
+  w.forward(tables().fwd[pi].data(), pc);
+  for (int l = 0; l < 64; ++l)
+    for (int c = 0; c < G::E; ++c) {
+      uint32_t v = csub(csub(w.x[l][c], pc.twop), pc.p);
+      out_std[G::j_p3(l, c)] = v;
+      out_mem[G::mem_p3(l, c)] = v;
+    }
+  return 0;
+}
+
+template <int LOGN>
+int ntt_inv(int pi, const uint32_t* in_std, uint32_t* out) {
+  using G = Geo<LOGN>;
+  PrimeConsts pc = host::make_prime_consts(pi, G::N);
+  static Wave<LOGN> w;
+  for (int l = 0; l < 64; ++l)
+    for (int c = 0; c < G::E; ++c) w.x[l][c] = in_std[G::j_p3(l, c)];
+  w.inverse(tables().inv[pi].data(), pc);
+  for (int l = 0; l < 64; ++l)
+    for (int e = 0; e < G::E; ++e)
+      out[G::j_p1(l, e)] = csub(mont_lazy(w.x[l][e], pc.ninv_r, pc.p, pc.npinv), pc.p);
+  return 0;
+}
+
+// out = a * b in Z_q[X]/(X^N+1), centred; exact via np primes
+template <int LOGN>
+int polymul(int np, uint64_t q, const int64_t* a, const int64_t* b, int64_t* out) {
+  using G = Geo<LOGN>;
+  CrtConsts C;
+  if (!host::make_crt_consts(q, C)) return -1;
+  PrimeConsts pc[kMaxPrimes];
+  for (int i = 0; i < kMaxPrimes; ++i) pc[i] = host::make_prime_consts(i, G::N);
+  static Wave<LOGN> wa, wb;
+  static uint32_t res[kMaxPrimes][64][G::E];
+  std::memset(res, 0, sizeof(res));
+  for (int pi = 0; pi < np; ++pi) {
+    for (int l = 0; l < 64; ++l)
+      for (int e = 0; e < G::E; ++e) {
+        wa.x[l][e] = lift((int32_t)a[G::j_p1(l, e)], pc[pi]);
+        wb.x[l][e] = lift((int32_t)b[G::j_p1(l, e)], pc[pi]);
+      }
+    wa.forward(tables().fwd[pi].data(), pc[pi]);
+    wb.forward(tables().fwd[pi].data(), pc[pi]);
+    for (int l = 0; l < 64; ++l)
+      for (int c = 0; c < G::E; ++c) {
+        uint32_t bs = mont_lazy(wb.x[l][c], pc[pi].ninv_r2, pc[pi].p, pc[pi].npinv);  // b^ * N^-1 * R
+        wa.x[l][c] = mac_add(0, wa.x[l][c], csub(bs, pc[pi].p), pc[pi]);
+      }
+    wa.inverse(tables().inv[pi].data(), pc[pi]);
+    std::memcpy(res[pi], wa.x, sizeof(wa.x));
+  }
+  for (int l = 0; l < 64; ++l)
+    for (int e = 0; e < G::E; ++e)
+      out[G::j_p1(l, e)] = crt_center(res[0][l][e], res[1][l][e], res[2][l][e], np, pc, C);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+int emul_ntt_fwd(int logn, int pi, const uint32_t* in, uint32_t* out_std, uint32_t* out_mem) {
+  switch (logn) {
+    case 9: return ntt_fwd<9>(pi, in, out_std, out_mem);
+    case 10: return ntt_fwd<10>(pi, in, out_std, out_mem);
+    case 11: return ntt_fwd<11>(pi, in, out_std, out_mem);
+  }
+  return -1;
+}
+int emul_ntt_inv(int logn, int pi, const uint32_t* in_std, uint32_t* out) {
+  switch (logn) {
+    case 9: return ntt_inv<9>(pi, in_std, out);
+    case 10: return ntt_inv<10>(pi, in_std, out);
+    case 11: return ntt_inv<11>(pi, in_std, out);
+  }
+  return -1;
+}
+int emul_polymul(int logn, int np, uint64_t q, const int64_t* a, const int64_t* b, int64_t* out) {
+  switch (logn) {
+    case 9: return polymul<9>(np, q, a, b, out);
+    case 10: return polymul<10>(np, q, a, b, out);
+    case 11: return polymul<11>(np, q, a, b, out);
+  }
+  return -1;
+}
+uint32_t emul_prime(int pi) { return kPrimes[pi]; }
+uint32_t emul_psi(int pi, uint32_t N) { return host::psi_for(pi, N); }
+double emul_capacity(int np) { return host::crt_capacity(np); }
+}

@@ -1,0 +1,114 @@
+"""CPU lane-emulation of the kernel core (ring_zk_amd/csrc/rzk_core.h) against the oracle.
+
+tests/emul/emul.cpp compiles the exact header the HIP kernels use with g++ and replays the 64 lanes
+of a wavefront phase by phase.  This checks the register/LDS geometry, the twiddle indexing, the
+Montgomery/lazy arithmetic and the CRT + mod-q centring bit-for-bit, without a GPU.  It is host
+logic testing: the product path never loads this emulator.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMUL_DIR = os.path.join(HERE, "emul")
+Q = O.Q_DEFAULT
+HALF = (Q - 1) // 2
+
+
+@pytest.fixture(scope="module")
+def emul():
+    so = os.path.join(EMUL_DIR, "libemul.so")
+    srcs = [os.path.join(EMUL_DIR, "emul.cpp"),
+            os.path.join(HERE, "..", "ring_zk_amd", "csrc", "rzk_core.h"),
+            os.path.join(HERE, "..", "ring_zk_amd", "csrc", "rzk_tables.h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wno-unknown-pragmas",
+                               "-o", so, srcs[0]])
+    L = C.CDLL(so)
+    L.emul_prime.restype = C.c_uint32
+    L.emul_psi.restype = C.c_uint32
+    L.emul_capacity.restype = C.c_double
+    return L
+
+
+def _u32p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+def _i64p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+@pytest.mark.parametrize("logn", [9, 10, 11])
+@pytest.mark.parametrize("pi", [0, 1, 2])
+def test_wave_ntt_matches_oracle_ntt(emul, logn, pi):
+    N = 1 << logn
+    p = emul.emul_prime(pi)
+    psi = emul.emul_psi(pi, N)
+    assert O.powmod(psi, N, p) == p - 1  # primitive 2N-th root of unity
+    rng = np.random.default_rng(100 * logn + pi)
+    a = rng.integers(0, p, N, dtype=np.uint32)
+    a[:4] = [0, 1, p - 1, p - 2]
+    out_std = np.empty(N, dtype=np.uint32)
+    out_mem = np.empty(N, dtype=np.uint32)
+    assert emul.emul_ntt_fwd(logn, pi, _u32p(a), _u32p(out_std), _u32p(out_mem)) == 0
+    ref = O.ntt_forward(a, p, psi)
+    assert np.array_equal(out_std, ref)
+    # the global-memory ("RZK NTT") layout is a permutation of the standard order
+    assert sorted(out_mem.tolist()) == sorted(ref.tolist())
+    back = np.empty(N, dtype=np.uint32)
+    assert emul.emul_ntt_inv(logn, pi, _u32p(out_std), _u32p(back)) == 0
+    assert np.array_equal(back, a)
+    assert np.array_equal(O.ntt_inverse(ref, p, psi), a)
+
+
+def _polymul(emul, logn, np_, a, b):
+    out = np.empty(1 << logn, dtype=np.int64)
+    a = np.ascontiguousarray(a, dtype=np.int64)
+    b = np.ascontiguousarray(b, dtype=np.int64)
+    assert emul.emul_polymul(logn, np_, C.c_uint64(Q), _i64p(a), _i64p(b), _i64p(out)) == 0
+    return out
+
+
+@pytest.mark.parametrize("logn", [9, 10, 11])
+def test_emulated_polymul_full_range(emul, logn, golden):
+    N = 1 << logn
+    rng = np.random.default_rng(logn)
+    a = rng.integers(-HALF, HALF + 1, N, dtype=np.int64)
+    b = rng.integers(-HALF, HALF + 1, N, dtype=np.int64)
+    assert np.array_equal(_polymul(emul, logn, 3, a, b), O.poly_mul(a, b))
+    for case in golden["extreme_products"] + golden["random_products"]:
+        if case["N"] == N:
+            assert _polymul(emul, logn, 3, case["a"], case["b"]).tolist() == case["out"], case.get("name")
+
+
+@pytest.mark.parametrize("logn", [9, 10])
+def test_emulated_polymul_fewer_primes(emul, logn):
+    """Small operands fit one or two primes: |result| <= ||a||_1 * ||b||_inf < capacity(np)."""
+    N = 1 << logn
+    rng = np.random.default_rng(77 + logn)
+    r = rng.integers(-1, 2, N, dtype=np.int64)           # ternary, like the commitment randomness
+    d = np.zeros(N, dtype=np.int64)                      # kappa-sparse challenge
+    pos = rng.choice(N, 36, replace=False)
+    d[pos] = rng.choice([-1, 1], 36)
+    assert 36 * 1 < emul.emul_capacity(1)
+    assert np.array_equal(_polymul(emul, logn, 1, r, d), O.poly_mul(r, d))
+    k = rng.integers(-HALF, HALF + 1, N, dtype=np.int64)  # full-range key entry
+    assert N * HALF < emul.emul_capacity(2)
+    assert np.array_equal(_polymul(emul, logn, 2, k, r), O.poly_mul(k, r))
+    y = np.trunc(rng.normal(0, 21780, N)).astype(np.int64)
+    assert float(np.abs(y).sum()) * HALF < emul.emul_capacity(2)
+    assert np.array_equal(_polymul(emul, logn, 2, k, y), O.poly_mul(k, y))
+    # boundary: values that land exactly on +/- (P-1)/2-ish are covered by the extreme-product test;
+    # here check negative results with a single prime
+    a = np.zeros(N, dtype=np.int64)
+    a[0] = -5
+    b = np.zeros(N, dtype=np.int64)
+    b[N - 1] = 7
+    b[0] = 3
+    assert np.array_equal(_polymul(emul, logn, 1, a, b), O.poly_mul(a, b))

@@ -1,0 +1,202 @@
+/*
+ * rzk.h — C ABI of the MI355X (gfx950) polynomial-ring backend for ring-zk.
+ *
+ * The reference crate (AlvinHon/ring-zk, /root/reference) has no plugin / FFI seam: all ring
+ * arithmetic of its protocols flows through four crate-private methods of `Mat`
+ * (src/mat.rs:95-178), one direct `Polynomial::mul` (src/prove/linear.rs:94) and the norm
+ * predicates of `Params` (src/params.rs:102-118).  This header is the boundary a thin Rust shim
+ * binds at exactly those places (INTEGRATION.md shows the `extern "C"` block and the replaced
+ * function bodies).  Each entry point below cites the reference code it replaces.
+ *
+ * Conventions
+ *   - A polynomial is N int64 coefficients, each the centred representative in
+ *     [-(q-1)/2, (q-1)/2] (what ZqI64<Q> stores; src/params.rs:122-126).  Inputs MUST be in that
+ *     range (the reference type guarantees it); outputs always are.
+ *   - Slabs are dense row-major: [batch][row][N].  A "batch" is B independent proofs that share
+ *     only the commitment key.
+ *   - Every function returns 0 (RZK_OK) or a negative status; nothing aborts.  The Rust shim turns
+ *     a non-zero status into panic!, preserving the reference's assert!/assert_eq! behaviour on
+ *     shape mismatch (src/mat.rs:103,129-130,154-155; src/commit.rs:95; src/prove/sum.rs:105).
+ *   - `*_dev` variants take device pointers and are asynchronous on the context's HIP stream;
+ *     the variants without the suffix take host pointers, copy in/out and are synchronous.
+ *   - One context per (GPU, host thread); calls on a context are serialised on its stream.
+ *   - The library never falls back to a CPU path: without a usable HIP device rzk_ctx_create fails.
+ */
+#ifndef RZK_H
+#define RZK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RZK_OK 0
+#define RZK_E_ARG (-1)         /* bad argument / shape mismatch (reference: assert panic)        */
+#define RZK_E_HIP (-2)         /* HIP runtime error, see rzk_last_error                           */
+#define RZK_E_STATE (-3)       /* e.g. key not loaded                                             */
+#define RZK_E_UNSUPPORTED (-4) /* ring degree / modulus / shape outside what the kernels support */
+
+typedef struct rzk_ctx rzk_ctx;
+
+/* Which block of the commitment key a matrix-vector product uses (src/commit.rs:19-25). */
+#define RZK_KEY_A1 0 /* a1: n x k        (rows 0..n-1 of [a1;a2])  */
+#define RZK_KEY_A2 1 /* a2: l x k        (rows n..n+l-1)           */
+#define RZK_KEY_A 2  /* [a1;a2]: (n+l) x k, as built at src/commit.rs:109-114 */
+
+/* ---- context ---------------------------------------------------------------------------------- */
+/* Mirrors Params<ZqI64<Q>> (src/params.rs:18-36) + const generics N and Q.
+ * q: ring modulus Q (odd, < 2^32; default 3515337053, src/params.rs:121), NOT Params.q.
+ * N: 512, 1024 or 2048.  Requires k > n >= 1, l >= 1, n + l <= k (src/params.rs:26-31).
+ * device: HIP device ordinal. */
+int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k, uint32_t l,
+                   uint32_t kappa, uint64_t b, int device);
+void rzk_ctx_destroy(rzk_ctx* ctx);
+/* Run on a caller-owned hipStream_t (e.g. PyTorch's current stream); NULL restores the own stream. */
+int rzk_ctx_set_stream(rzk_ctx* ctx, void* hip_stream);
+int rzk_ctx_synchronize(rzk_ctx* ctx);
+const char* rzk_last_error(const rzk_ctx* ctx);
+/* sigma, 4*sigma*floor(sqrt N), 2*sigma*floor(sqrt N)   (src/params.rs:94-98,104,114) */
+uint64_t rzk_sigma(const rzk_ctx* ctx);
+uint64_t rzk_commit_bound(const rzk_ctx* ctx);
+uint64_t rzk_verify_bound(const rzk_ctx* ctx);
+
+/* ---- key ----------------------------------------------------------------------------------------- */
+/* CommitmentKey (src/commit.rs:19-25): a = [a1;a2], (n+l)*k polynomials row-major, exactly the
+ * matrix commit() assembles at src/commit.rs:109-114 (identity / zero blocks included).  The key is
+ * transformed once into the NTT domain of the three auxiliary primes and kept resident in HBM;
+ * entries equal to 0 or 1 are recognised and skipped / turned into plain additions. */
+int rzk_key_load(rzk_ctx* ctx, const int64_t* a_host);
+int rzk_key_load_dev(rzk_ctx* ctx, const int64_t* a_dev);
+
+/* ---- ring / Mat primitives (the Mat seam) ------------------------------------------------------------ */
+/* Polynomial::mul (src/prove/linear.rs:94; src/mat.rs:110,176): out[i] = a[i] * b[i], count polys */
+int rzk_polymul_batch(rzk_ctx* ctx, const int64_t* a, const int64_t* b, int64_t* out, size_t count);
+int rzk_polymul_batch_dev(rzk_ctx* ctx, const int64_t* a, const int64_t* b, int64_t* out, size_t count);
+/* Mat::dot with the key on the left (src/mat.rs:95-115; call sites src/commit.rs:125,
+ * src/prove/open.rs:97,171 ...): out[b] = KEY(which) . v[b] (+ addend[b] when addend != NULL, the
+ * `.add(&z)` of src/commit.rs:125).  v: [B][k][N]; out, addend: [B][rows(which)][N]. */
+int rzk_matvec_batch(rzk_ctx* ctx, int which, const int64_t* v, const int64_t* addend, int64_t* out,
+                     size_t B);
+int rzk_matvec_batch_dev(rzk_ctx* ctx, int which, const int64_t* v, const int64_t* addend,
+                         int64_t* out, size_t B);
+/* Mat::componentwise_mul (src/mat.rs:168-178): out[b][i] = m[b][i] * p[b].  m,out: [B][rows][N]; p: [B][N] */
+int rzk_cmul_batch(rzk_ctx* ctx, const int64_t* m, uint32_t rows, const int64_t* p, int64_t* out, size_t B);
+int rzk_cmul_batch_dev(rzk_ctx* ctx, const int64_t* m, uint32_t rows, const int64_t* p, int64_t* out,
+                       size_t B);
+/* Mat::add / Mat::sub (src/mat.rs:122-140, 147-165) on `count` polynomials */
+int rzk_add_batch(rzk_ctx* ctx, const int64_t* a, const int64_t* b, int64_t* out, size_t count);
+int rzk_add_batch_dev(rzk_ctx* ctx, const int64_t* a, const int64_t* b, int64_t* out, size_t count);
+int rzk_sub_batch(rzk_ctx* ctx, const int64_t* a, const int64_t* b, int64_t* out, size_t count);
+int rzk_sub_batch_dev(rzk_ctx* ctx, const int64_t* a, const int64_t* b, int64_t* out, size_t count);
+/* Params::check_{commit,verify}_constraint (src/params.rs:102-118 -> src/polynomial.rs:60-73):
+ * ok[b] = 1 iff every one of the `rows` polynomials of proof b has floor(sqrt(sum c^2)) <= bound */
+int rzk_norm2_le_batch(rzk_ctx* ctx, const int64_t* v, uint32_t rows, uint64_t bound, uint8_t* ok, size_t B);
+int rzk_norm2_le_batch_dev(rzk_ctx* ctx, const int64_t* v, uint32_t rows, uint64_t bound, uint8_t* ok,
+                           size_t B);
+/* derived Mat PartialEq (src/mat.rs:11; `lhs == rhs` at src/prove/open.rs:173): eq[b] = all rows equal */
+int rzk_eq_batch(rzk_ctx* ctx, const int64_t* a, const int64_t* b, uint32_t rows, uint8_t* eq, size_t B);
+int rzk_eq_batch_dev(rzk_ctx* ctx, const int64_t* a, const int64_t* b, uint32_t rows, uint8_t* eq, size_t B);
+
+/* ---- batched transforms over one auxiliary prime (no reference counterpart) ---------- */
+/* in/out: `count` residue polynomials of N uint32 in [0,p).  Forward output / inverse input use the
+ * library's NTT-domain layout (rzk_ntt_layout_index).  prime: 0..2. */
+int rzk_ntt_forward_batch(rzk_ctx* ctx, int prime, const uint32_t* in, uint32_t* out, size_t count);
+int rzk_ntt_forward_batch_dev(rzk_ctx* ctx, int prime, const uint32_t* in, uint32_t* out, size_t count);
+int rzk_ntt_inverse_batch(rzk_ctx* ctx, int prime, const uint32_t* in, uint32_t* out, size_t count);
+int rzk_ntt_inverse_batch_dev(rzk_ctx* ctx, int prime, const uint32_t* in, uint32_t* out, size_t count);
+uint32_t rzk_ntt_prime(int prime);
+/* primitive 2N-th root of unity used for ring degree N */
+uint32_t rzk_ntt_psi(int prime, uint32_t N);
+/* position, in the NTT-domain layout, of element j of the standard bit-reversed-order transform */
+uint32_t rzk_ntt_layout_index(uint32_t N, uint32_t j);
+
+/* ---- OpenProof phases (src/prove/open.rs) --------------------------------------------------------- */
+/* OpenProofProver::commit (open.rs:80-103) with the randomness supplied by the caller:
+ * c = [a1;a2].r + [0;x] (commit.rs:125), t = a1.y (open.rs:97); ok[b] = check_commit_constraint(r)
+ * (commit.rs:98-107: the reference resamples r until it holds; here the caller does).
+ * x:[B][l][N] r,y:[B][k][N] -> c:[B][n+l][N] t:[B][n][N] ok:[B] */
+int rzk_open_commit_batch(rzk_ctx* ctx, const int64_t* x, const int64_t* r, const int64_t* y,
+                          int64_t* c, int64_t* t, uint8_t* ok, size_t B);
+int rzk_open_commit_batch_dev(rzk_ctx* ctx, const int64_t* x, const int64_t* r, const int64_t* y,
+                              int64_t* c, int64_t* t, uint8_t* ok, size_t B);
+/* OpenProofProver::create_response (open.rs:107-117): z = y + r (.) d.   d:[B][N] z:[B][k][N] */
+int rzk_open_response_batch(rzk_ctx* ctx, const int64_t* y, const int64_t* r, const int64_t* d,
+                            int64_t* z, size_t B);
+int rzk_open_response_batch_dev(rzk_ctx* ctx, const int64_t* y, const int64_t* r, const int64_t* d,
+                                int64_t* z, size_t B);
+/* OpenProofVerifier::verify (open.rs:162-174) on the full commitment c (c1 split as
+ * Commitment::c1_c2 does, commit.rs:213-218; requires n == l):
+ * accept[b] = check_verify_constraint(z) && a1.z == t + c1 (.) d */
+int rzk_open_verify_batch(rzk_ctx* ctx, const int64_t* z, const int64_t* t, const int64_t* c,
+                          const int64_t* d, uint8_t* accept, size_t B);
+int rzk_open_verify_batch_dev(rzk_ctx* ctx, const int64_t* z, const int64_t* t, const int64_t* c,
+                              const int64_t* d, uint8_t* accept, size_t B);
+
+/* ---- LinearProof phases (src/prove/linear.rs) -------------------------------------------------------- */
+/* commit (linear.rs:82-140): gx = g*x; cp = commit(gx; rp); c = commit(x; r); t = a1.y; tp = a1.yp;
+ * u = (a2.y) (.) g - a2.yp.   ok[b]: bit0 = constraint(r), bit1 = constraint(rp).
+ * g:[B][N] x:[B][l][N] r,rp,y,yp:[B][k][N] -> c,cp:[B][n+l][N] t,tp:[B][n][N] u:[B][l][N] */
+int rzk_linear_commit_batch(rzk_ctx* ctx, const int64_t* g, const int64_t* x, const int64_t* r,
+                            const int64_t* rp, const int64_t* y, const int64_t* yp, int64_t* c,
+                            int64_t* cp, int64_t* t, int64_t* tp, int64_t* u, uint8_t* ok, size_t B);
+int rzk_linear_commit_batch_dev(rzk_ctx* ctx, const int64_t* g, const int64_t* x, const int64_t* r,
+                                const int64_t* rp, const int64_t* y, const int64_t* yp, int64_t* c,
+                                int64_t* cp, int64_t* t, int64_t* tp, int64_t* u, uint8_t* ok, size_t B);
+/* create_response (linear.rs:144-158): z = y + r(.)d, zp = yp + rp(.)d */
+int rzk_linear_response_batch(rzk_ctx* ctx, const int64_t* y, const int64_t* yp, const int64_t* r,
+                              const int64_t* rp, const int64_t* d, int64_t* z, int64_t* zp, size_t B);
+int rzk_linear_response_batch_dev(rzk_ctx* ctx, const int64_t* y, const int64_t* yp, const int64_t* r,
+                                  const int64_t* rp, const int64_t* d, int64_t* z, int64_t* zp, size_t B);
+/* verify (linear.rs:213-250) */
+int rzk_linear_verify_batch(rzk_ctx* ctx, const int64_t* z, const int64_t* zp, const int64_t* c,
+                            const int64_t* cp, const int64_t* g, const int64_t* t, const int64_t* tp,
+                            const int64_t* u, const int64_t* d, uint8_t* accept, size_t B);
+int rzk_linear_verify_batch_dev(rzk_ctx* ctx, const int64_t* z, const int64_t* zp, const int64_t* c,
+                                const int64_t* cp, const int64_t* g, const int64_t* t, const int64_t* tp,
+                                const int64_t* u, const int64_t* d, uint8_t* accept, size_t B);
+
+/* ---- SumProof phases (src/prove/sum.rs), V summands per proof ----------------------------------------- */
+/* commit (sum.rs:99-178).  gs:[B][V][N] xs:[B][V][l][N] rs,ys:[B][V][k][N] rp,yp:[B][k][N]
+ * -> cs:[B][V][n+l][N] cp:[B][n+l][N] ts:[B][V][n][N] tp:[B][n][N] u:[B][l][N]; ok[b] = all constraints */
+int rzk_sum_commit_batch(rzk_ctx* ctx, uint32_t V, const int64_t* gs, const int64_t* xs,
+                         const int64_t* rs, const int64_t* rp, const int64_t* ys, const int64_t* yp,
+                         int64_t* cs, int64_t* cp, int64_t* ts, int64_t* tp, int64_t* u, uint8_t* ok,
+                         size_t B);
+int rzk_sum_commit_batch_dev(rzk_ctx* ctx, uint32_t V, const int64_t* gs, const int64_t* xs,
+                             const int64_t* rs, const int64_t* rp, const int64_t* ys, const int64_t* yp,
+                             int64_t* cs, int64_t* cp, int64_t* ts, int64_t* tp, int64_t* u,
+                             uint8_t* ok, size_t B);
+/* create_response (sum.rs:182-200) */
+int rzk_sum_response_batch(rzk_ctx* ctx, uint32_t V, const int64_t* ys, const int64_t* yp,
+                           const int64_t* rs, const int64_t* rp, const int64_t* d, int64_t* zs,
+                           int64_t* zp, size_t B);
+int rzk_sum_response_batch_dev(rzk_ctx* ctx, uint32_t V, const int64_t* ys, const int64_t* yp,
+                               const int64_t* rs, const int64_t* rp, const int64_t* d, int64_t* zs,
+                               int64_t* zp, size_t B);
+/* verify (sum.rs:257-320) */
+int rzk_sum_verify_batch(rzk_ctx* ctx, uint32_t V, const int64_t* zs, const int64_t* zp,
+                         const int64_t* cs, const int64_t* cp, const int64_t* gs, const int64_t* ts,
+                         const int64_t* tp, const int64_t* u, const int64_t* d, uint8_t* accept,
+                         size_t B);
+int rzk_sum_verify_batch_dev(rzk_ctx* ctx, uint32_t V, const int64_t* zs, const int64_t* zp,
+                             const int64_t* cs, const int64_t* cp, const int64_t* gs, const int64_t* ts,
+                             const int64_t* tp, const int64_t* u, const int64_t* d, uint8_t* accept,
+                             size_t B);
+
+/* ---- instrumentation (bench.py) ------------------------------------------------------------------------- */
+/* Times `iters` launches of the batched forward NTT kernel with HIP events on the context stream and
+ * returns the average kernel duration in microseconds (negative status on error). */
+double rzk_bench_ntt_forward_dev(rzk_ctx* ctx, int prime, const uint32_t* in, uint32_t* out,
+                                 size_t count, int iters);
+/* HIP-event timing of the last phase call's dominant kernel is exposed through these counters:
+ * accumulated microseconds and launch count of the row kernel since the last reset. */
+int rzk_prof_reset(rzk_ctx* ctx);
+int rzk_prof_enable(rzk_ctx* ctx, int on);
+int rzk_prof_read(rzk_ctx* ctx, double* row_kernel_us, uint64_t* row_kernel_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RZK_H */

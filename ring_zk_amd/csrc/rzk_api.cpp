@@ -1,0 +1,1116 @@
+// rzk_api.cpp — the C ABI declared in include/rzk.h: context, resident key, row programs of every
+// protocol phase, host-pointer wrappers.  Compiled with hipcc together with rzk_kernels.hip into
+// ring_zk_amd/librzk_hip.so.  There is no CPU fallback anywhere in this file: every entry point
+// launches HIP kernels on the context's device or returns an error status.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/rzk.h"
+#include "rzk_core.h"
+#include "rzk_dev.h"
+#include "rzk_tables.h"
+
+using namespace rzk;
+
+namespace {
+
+enum KeyClass : uint8_t { KC_ZERO = 0, KC_ONE = 1, KC_GENERAL = 2 };
+
+enum ProgId : int {
+  PG_MATVEC = 0,      // variant = which*2 + has_addend
+  PG_POLYMUL,
+  PG_CMUL,            // variant = rows
+  PG_OPEN_COMMIT,
+  PG_RESPONSE,        // variant = number of (y,r,z) triples sharing d (1 = open, 2 = linear)
+  PG_A1_RELATION,     // a1.z - c1(.)d - t == 0   (open / linear / sum verify)
+  PG_LIN_COMMIT2,
+  PG_LIN_U,
+  PG_LIN_V1,
+  PG_LIN_V2,
+  PG_SUM_XP,          // variant = V
+  PG_SUM_U,           // variant = V
+  PG_SUM_W2,          // variant = V
+  PG_SUM_V3,          // variant = V
+};
+
+struct DevProg {
+  Program* d = nullptr;
+  uint32_t nrows = 0;
+};
+
+struct Arena {   // grow-only device buffer
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct rzk_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  int num_cus = 256;
+  int64_t q = 0;
+  uint32_t N = 0, logn = 0, n = 0, k = 0, l = 0, kappa = 0;
+  uint64_t b = 0;
+  uint64_t sigma = 0, commit_bound = 0, verify_bound = 0;
+  DevTables hT{};
+  DevTables* dT = nullptr;
+  uint32_t* d_tw = nullptr;
+  // key
+  bool key_loaded = false;
+  std::vector<uint8_t> key_class;     // (n+l)*k
+  std::vector<int32_t> key_entry;     // index into the NTT-domain store, -1 if not GENERAL
+  uint32_t n_general = 0;
+  uint32_t* d_key_ntt = nullptr;
+  double* d_key_inf = nullptr;
+  std::map<std::pair<int, uint32_t>, DevProg> progs;
+  Arena ws, stage;
+  std::string err;
+  // profiling of the row kernel with HIP events on the launch stream
+  bool prof = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  size_t prof_used = 0;
+  double prof_us = 0.0;
+  uint64_t prof_launches = 0;
+};
+
+namespace {
+
+#define HIPCHK(ctx, expr)                                                                        \
+  do {                                                                                           \
+    hipError_t e_ = (expr);                                                                      \
+    if (e_ != hipSuccess) {                                                                      \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                            \
+      return RZK_E_HIP;                                                                          \
+    }                                                                                            \
+  } while (0)
+
+int fail(rzk_ctx* c, int code, const char* msg) {
+  if (c) c->err = msg;
+  return code;
+}
+
+uint64_t isqrt_u64(uint64_t x) {
+  uint64_t r = (uint64_t)std::sqrt((long double)x);
+  while ((unsigned __int128)r * r > x) --r;
+  while ((unsigned __int128)(r + 1) * (r + 1) <= x) ++r;
+  return r;
+}
+
+LaunchCfg cfg_of(rzk_ctx* c) {
+  (void)hipSetDevice(c->device);   // the calling thread may have another current device
+  return LaunchCfg{(void*)c->stream, c->num_cus};
+}
+
+int arena_reserve(rzk_ctx* c, Arena& a, size_t bytes) {
+  if (bytes <= a.cap) return RZK_OK;
+  // grow-only; happens outside steady state.  The old block may still be in use by queued work.
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (a.p) HIPCHK(c, hipFree(a.p));
+  a.p = nullptr;
+  a.cap = 0;
+  size_t want = bytes + bytes / 4;
+  HIPCHK(c, hipMalloc(&a.p, want));
+  a.cap = want;
+  return RZK_OK;
+}
+
+// ---- program builder ------------------------------------------------------------------------------------------
+struct PB {
+  Program p{};
+  bool overflow = false;
+  int cur = -1;
+  void begin_row(uint8_t out_op, uint32_t out_off, uint8_t mode) {
+    if (p.nrows >= (uint32_t)kMaxRows) { overflow = true; return; }
+    cur = (int)p.nrows++;
+    Row& r = p.rows[cur];
+    r.term0 = (uint16_t)p.nterms;
+    r.add0 = (uint16_t)p.nadds;
+    r.nterms = r.nadds = 0;
+    r.out_op = out_op;
+    r.out_off = (uint16_t)out_off;
+    r.mode = mode;
+    if (out_off > 0xffff) overflow = true;
+  }
+  void key_term(int sign, uint32_t entry, uint8_t vop, uint32_t voff) {
+    if (cur < 0 || p.nterms >= (uint32_t)kMaxTerms || entry > 0xffff || voff > 0xffff) { overflow = true; return; }
+    Term& t = p.terms[p.nterms++];
+    t.kind = TERM_KEY;
+    t.sign = (int8_t)sign;
+    t.a_op = 0;
+    t.a_off = (uint16_t)entry;
+    t.b_op = vop;
+    t.b_off = (uint16_t)voff;
+    p.rows[cur].nterms++;
+  }
+  void vec_term(int sign, uint8_t aop, uint32_t aoff, uint8_t bop, uint32_t boff) {
+    if (cur < 0 || p.nterms >= (uint32_t)kMaxTerms || aoff > 0xffff || boff > 0xffff) { overflow = true; return; }
+    Term& t = p.terms[p.nterms++];
+    t.kind = TERM_VEC;
+    t.sign = (int8_t)sign;
+    t.a_op = aop;
+    t.a_off = (uint16_t)aoff;
+    t.b_op = bop;
+    t.b_off = (uint16_t)boff;
+    p.rows[cur].nterms++;
+  }
+  void add(int sign, uint8_t op, uint32_t off) {
+    if (cur < 0 || p.nadds >= (uint32_t)kMaxAdds || off > 0xffff) { overflow = true; return; }
+    AddTerm& a = p.adds[p.nadds++];
+    a.op = op;
+    a.sign = (int8_t)sign;
+    a.off = (uint16_t)off;
+    p.rows[cur].nadds++;
+  }
+};
+
+// sign * (row `krow` of [a1;a2]) . v, v = operand (vop, voff .. voff+k-1): skips zero entries, turns
+// entries equal to 1 into plain additions (the identity blocks of commit.rs:38-57), products otherwise.
+void key_row(rzk_ctx* c, PB& pb, int sign, uint32_t krow, uint8_t vop, uint32_t voff) {
+  for (uint32_t j = 0; j < c->k; ++j) {
+    const uint32_t idx = krow * c->k + j;
+    switch (c->key_class[idx]) {
+      case KC_ZERO: break;
+      case KC_ONE: pb.add(sign, vop, voff + j); break;
+      default: pb.key_term(sign, (uint32_t)c->key_entry[idx], vop, voff + j); break;
+    }
+  }
+}
+
+int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
+  const uint32_t n = c->n, k = c->k, l = c->l;
+  switch (id) {
+    case PG_MATVEC: {   // ops: 0 = v[k], 1 = addend[rows], 2 = out[rows]
+      const uint32_t which = var >> 1;
+      const bool has_add = var & 1;
+      const uint32_t r0 = which == RZK_KEY_A2 ? n : 0;
+      const uint32_t rows = which == RZK_KEY_A1 ? n : (which == RZK_KEY_A2 ? l : n + l);
+      for (uint32_t i = 0; i < rows; ++i) {
+        pb.begin_row(2, i, MODE_STORE);
+        key_row(c, pb, +1, r0 + i, 0, 0);
+        if (has_add) pb.add(+1, 1, i);
+      }
+      break;
+    }
+    case PG_POLYMUL:   // ops: 0 = a, 1 = b, 2 = out
+      pb.begin_row(2, 0, MODE_STORE);
+      pb.vec_term(+1, 0, 0, 1, 0);
+      break;
+    case PG_CMUL:      // ops: 0 = m[rows], 1 = p, 2 = out[rows]   (mat.rs:168-178)
+      for (uint32_t i = 0; i < var; ++i) {
+        pb.begin_row(2, i, MODE_STORE);
+        pb.vec_term(+1, 0, i, 1, 0);
+      }
+      break;
+    case PG_OPEN_COMMIT:   // ops: 0 = x[l], 1 = r[k], 2 = y[k], 3 = c[n+l], 4 = t[n]
+      for (uint32_t i = 0; i < n + l; ++i) {   // commit.rs:125: c = [a1;a2].r + [0_n ; x]
+        pb.begin_row(3, i, MODE_STORE);
+        key_row(c, pb, +1, i, 1, 0);
+        if (i >= n) pb.add(+1, 0, i - n);
+      }
+      for (uint32_t i = 0; i < n; ++i) {       // open.rs:97: t = a1.y
+        pb.begin_row(4, i, MODE_STORE);
+        key_row(c, pb, +1, i, 2, 0);
+      }
+      break;
+    case PG_RESPONSE:   // ops: 0 = d, then per triple s: 1+3s = y[k], 2+3s = r[k], 3+3s = z[k]
+      for (uint32_t s = 0; s < var; ++s)
+        for (uint32_t i = 0; i < k; ++i) {      // open.rs:113-115: z = y + r (.) d
+          pb.begin_row((uint8_t)(3 + 3 * s), i, MODE_STORE);
+          pb.vec_term(+1, 0, 0, (uint8_t)(2 + 3 * s), i);
+          pb.add(+1, (uint8_t)(1 + 3 * s), i);
+        }
+      break;
+    case PG_A1_RELATION:   // ops: 0 = z[k], 1 = t[n], 2 = c[n+l], 3 = d ; flags &= (a1.z == t + c1(.)d)
+      // c1 = first l rows of c (Commitment::c1_c2 -> split_rows(n), commit.rs:213-218, mat.rs:203-213);
+      // Mat::add requires it to have n rows, so n == l is checked by the caller.
+      for (uint32_t i = 0; i < n; ++i) {
+        pb.begin_row(0, 0, MODE_ZERO);
+        key_row(c, pb, +1, i, 0, 0);
+        pb.vec_term(-1, 3, 0, 2, i);
+        pb.add(-1, 1, i);
+      }
+      break;
+    case PG_LIN_COMMIT2:
+      // ops: 0 = x[l], 1 = gx[l], 2 = r[k], 3 = rp[k], 4 = y[k], 5 = yp[k],
+      //      6 = c[n+l], 7 = cp[n+l], 8 = t[n], 9 = tp[n], 10 = a2y[l]
+      for (uint32_t i = 0; i < n + l; ++i) {   // linear.rs:97: c = commit(x; r)
+        pb.begin_row(6, i, MODE_STORE);
+        key_row(c, pb, +1, i, 2, 0);
+        if (i >= n) pb.add(+1, 0, i - n);
+      }
+      for (uint32_t i = 0; i < n + l; ++i) {   // linear.rs:96: cp = commit(g*x; rp)
+        pb.begin_row(7, i, MODE_STORE);
+        key_row(c, pb, +1, i, 3, 0);
+        if (i >= n) pb.add(+1, 1, i - n);
+      }
+      for (uint32_t i = 0; i < n; ++i) {       // linear.rs:118
+        pb.begin_row(8, i, MODE_STORE);
+        key_row(c, pb, +1, i, 4, 0);
+      }
+      for (uint32_t i = 0; i < n; ++i) {       // linear.rs:121
+        pb.begin_row(9, i, MODE_STORE);
+        key_row(c, pb, +1, i, 5, 0);
+      }
+      for (uint32_t i = 0; i < l; ++i) {       // a2.y, reduced mod q before it meets g (linear.rs:124-127)
+        pb.begin_row(10, i, MODE_STORE);
+        key_row(c, pb, +1, n + i, 4, 0);
+      }
+      break;
+    case PG_LIN_U:   // ops: 0 = a2y[l], 1 = g, 2 = yp[k], 3 = u[l] : u = a2y(.)g - a2.yp (linear.rs:124-129)
+      for (uint32_t i = 0; i < l; ++i) {
+        pb.begin_row(3, i, MODE_STORE);
+        pb.vec_term(+1, 0, i, 1, 0);
+        key_row(c, pb, -1, n + i, 2, 0);
+      }
+      break;
+    case PG_LIN_V1:
+      // ops: 0 = z[k], 1 = zp[k], 2 = t[n], 3 = tp[n], 4 = c[n+l], 5 = cp[n+l], 6 = d, 7 = g,
+      //      8 = w1[l] (a2.z), 9 = w2[l] (c2(.)g - c2p)
+      for (uint32_t i = 0; i < n; ++i) {       // linear.rs:225-229
+        pb.begin_row(0, 0, MODE_ZERO);
+        key_row(c, pb, +1, i, 0, 0);
+        pb.vec_term(-1, 6, 0, 4, i);
+        pb.add(-1, 2, i);
+      }
+      for (uint32_t i = 0; i < n; ++i) {       // linear.rs:231-235
+        pb.begin_row(0, 0, MODE_ZERO);
+        key_row(c, pb, +1, i, 1, 0);
+        pb.vec_term(-1, 6, 0, 5, i);
+        pb.add(-1, 3, i);
+      }
+      for (uint32_t i = 0; i < l; ++i) {       // a2.z (linear.rs:238-241), reduced before (.)g
+        pb.begin_row(8, i, MODE_STORE);
+        key_row(c, pb, +1, n + i, 0, 0);
+      }
+      for (uint32_t i = 0; i < l; ++i) {       // c2(.)g - c2p (linear.rs:243-246); c2 = last n rows of c
+        pb.begin_row(9, i, MODE_STORE);
+        pb.vec_term(+1, 4, l + i, 7, 0);
+        pb.add(-1, 5, l + i);
+      }
+      break;
+    case PG_LIN_V2:
+      // ops: 0 = w1[l], 1 = w2[l], 2 = g, 3 = d, 4 = zp[k], 5 = u[l]
+      // w1(.)g - a2.zp - w2(.)d - u == 0   (linear.rs:237-249)
+      for (uint32_t i = 0; i < l; ++i) {
+        pb.begin_row(0, 0, MODE_ZERO);
+        pb.vec_term(+1, 0, i, 2, 0);
+        key_row(c, pb, -1, n + i, 4, 0);
+        pb.vec_term(-1, 3, 0, 1, i);
+        pb.add(-1, 5, i);
+      }
+      break;
+    case PG_SUM_XP:   // ops: 0 = xs[V*l], 1 = gs[V], 2 = xp[l] : xp = sum_i x_i (.) g_i (sum.rs:107-115)
+      for (uint32_t j = 0; j < l; ++j) {
+        pb.begin_row(2, j, MODE_STORE);
+        for (uint32_t i = 0; i < var; ++i) pb.vec_term(+1, 0, i * l + j, 1, i);
+      }
+      break;
+    case PG_SUM_U:    // ops: 0 = w[V*l] (a2.y_i), 1 = gs[V], 2 = yp[k], 3 = u[l]   (sum.rs:154-160)
+      for (uint32_t j = 0; j < l; ++j) {
+        pb.begin_row(3, j, MODE_STORE);
+        for (uint32_t i = 0; i < var; ++i) pb.vec_term(+1, 0, i * l + j, 1, i);
+        key_row(c, pb, -1, n + j, 2, 0);
+      }
+      break;
+    case PG_SUM_W2:   // ops: 0 = cs[V*(n+l)], 1 = gs[V], 2 = cp[n+l], 3 = w2[l] : sum_i c2_i(.)g_i - c2p (sum.rs:309-316)
+      for (uint32_t j = 0; j < l; ++j) {
+        pb.begin_row(3, j, MODE_STORE);
+        for (uint32_t i = 0; i < var; ++i) pb.vec_term(+1, 0, i * (n + l) + l + j, 1, i);
+        pb.add(-1, 2, l + j);
+      }
+      break;
+    case PG_SUM_V3:   // ops: 0 = w1[V*l] (a2.z_i), 1 = gs[V], 2 = zp[k], 3 = w2[l], 4 = d, 5 = u[l]   (sum.rs:301-319)
+      for (uint32_t j = 0; j < l; ++j) {
+        pb.begin_row(0, 0, MODE_ZERO);
+        for (uint32_t i = 0; i < var; ++i) pb.vec_term(+1, 0, i * l + j, 1, i);
+        key_row(c, pb, -1, n + j, 2, 0);
+        pb.vec_term(-1, 4, 0, 3, j);
+        pb.add(-1, 5, j);
+      }
+      break;
+    default: return RZK_E_ARG;
+  }
+  return RZK_OK;
+}
+
+int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
+  const bool needs_key = !(id == PG_POLYMUL || id == PG_CMUL || id == PG_RESPONSE || id == PG_SUM_XP ||
+                           id == PG_SUM_W2);
+  if (needs_key && !c->key_loaded) return fail(c, RZK_E_STATE, "commitment key not loaded");
+  auto it = c->progs.find({id, var});
+  if (it != c->progs.end()) {
+    out = it->second;
+    return RZK_OK;
+  }
+  PB pb;
+  int rc = build_program(c, id, var, pb);
+  if (rc != RZK_OK) return fail(c, rc, "unknown program");
+  if (pb.overflow) return fail(c, RZK_E_UNSUPPORTED, "shape exceeds row-program capacity");
+  DevProg dp;
+  HIPCHK(c, hipMalloc((void**)&dp.d, sizeof(Program)));
+  HIPCHK(c, hipMemcpyAsync(dp.d, &pb.p, sizeof(Program), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));   // pb.p is a stack object; one-off per (program, shape)
+  dp.nrows = pb.p.nrows;
+  c->progs[{id, var}] = dp;
+  out = dp;
+  return RZK_OK;
+}
+
+void drop_programs(rzk_ctx* c) {
+  for (auto& kv : c->progs)
+    if (kv.second.d) (void)hipFree(kv.second.d);
+  c->progs.clear();
+}
+
+struct OpSpec {
+  const int64_t* base;
+  uint32_t stride;
+  uint32_t div;
+};
+
+int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& specs, uint8_t* flags,
+                uint32_t flag_div, uint64_t batch) {
+  DevProg dp;
+  int rc = get_program(c, id, var, dp);
+  if (rc != RZK_OK) return rc;
+  if (specs.size() > (size_t)kMaxOperands) return fail(c, RZK_E_ARG, "too many operands");
+  Operands ops{};
+  for (size_t i = 0; i < specs.size(); ++i) {
+    ops.base[i] = const_cast<int64_t*>(specs[i].base);
+    ops.stride[i] = specs[i].stride;
+    ops.div[i] = specs[i].div ? specs[i].div : 1;
+  }
+  for (size_t i = specs.size(); i < (size_t)kMaxOperands; ++i) ops.div[i] = 1;
+  ops.flag_div = flag_div ? flag_div : 1;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (c->prof) {
+    if (c->prof_used == c->prof_events.size()) {
+      hipEvent_t a, b;
+      HIPCHK(c, hipEventCreate(&a));
+      HIPCHK(c, hipEventCreate(&b));
+      c->prof_events.push_back({a, b});
+    }
+    e0 = c->prof_events[c->prof_used].first;
+    e1 = c->prof_events[c->prof_used].second;
+    c->prof_used++;
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+  }
+  int lrc = launch_row_program((int)c->logn, cfg_of(c), dp.d, dp.nrows, ops, c->d_key_ntt, c->d_key_inf,
+                               c->dT, flags, batch);
+  if (lrc != 0) {
+    c->err = std::string("row kernel launch: ") + hipGetErrorString((hipError_t)lrc);
+    return RZK_E_HIP;
+  }
+  if (c->prof) HIPCHK(c, hipEventRecord(e1, c->stream));
+  return RZK_OK;
+}
+
+int check_launch(rzk_ctx* c, int lrc, const char* what) {
+  if (lrc == 0) return RZK_OK;
+  c->err = std::string(what) + ": " + (lrc > 0 ? hipGetErrorString((hipError_t)lrc) : "bad ring degree");
+  return RZK_E_HIP;
+}
+
+// (bound+1)^2 as hi:lo
+void norm_limit(uint64_t bound, uint64_t& hi, uint64_t& lo) {
+  unsigned __int128 v = (unsigned __int128)(bound + 1) * (bound + 1);
+  hi = (uint64_t)(v >> 64);
+  lo = (uint64_t)v;
+}
+
+int run_norm(rzk_ctx* c, const int64_t* v, uint32_t rows, uint64_t bound, uint8_t* ok, uint64_t B, int mode,
+             int shift) {
+  if (bound >= (1ull << 32)) return fail(c, RZK_E_ARG, "norm bound must be below 2^32");
+  uint64_t hi, lo;
+  norm_limit(bound, hi, lo);
+  return check_launch(c, launch_norm((int)c->logn, cfg_of(c), v, rows, hi, lo, ok, B, mode, shift), "norm kernel");
+}
+
+// ---- host-pointer plumbing ---------------------------------------------------------------------------------
+struct HostBuf {
+  const void* in;   // host source (nullptr for pure outputs)
+  void* out;        // host destination (nullptr for pure inputs)
+  size_t bytes;
+  void* dev;        // filled by stage_in
+};
+
+int stage_in(rzk_ctx* c, std::vector<HostBuf>& bufs) {
+  size_t total = 0;
+  for (auto& b : bufs) total += (b.bytes + 255) & ~size_t(255);
+  int rc = arena_reserve(c, c->stage, total);
+  if (rc != RZK_OK) return rc;
+  size_t off = 0;
+  for (auto& b : bufs) {
+    b.dev = (char*)c->stage.p + off;
+    off += (b.bytes + 255) & ~size_t(255);
+    if (b.in && b.bytes) HIPCHK(c, hipMemcpyAsync(b.dev, b.in, b.bytes, hipMemcpyHostToDevice, c->stream));
+  }
+  return RZK_OK;
+}
+
+int stage_out(rzk_ctx* c, std::vector<HostBuf>& bufs) {
+  for (auto& b : bufs)
+    if (b.out && b.bytes) HIPCHK(c, hipMemcpyAsync(b.out, b.dev, b.bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return RZK_OK;
+}
+
+size_t polys(const rzk_ctx* c, size_t count) { return count * (size_t)c->N * sizeof(int64_t); }
+
+}  // namespace
+
+// =================================================================================================
+// context
+// =================================================================================================
+extern "C" {
+
+int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k, uint32_t l, uint32_t kappa,
+                   uint64_t b, int device) {
+  if (!out) return RZK_E_ARG;
+  *out = nullptr;
+  if (N != 512 && N != 1024 && N != 2048) return RZK_E_UNSUPPORTED;
+  if (n < 1 || l < 1 || k <= n || n + l > k) return RZK_E_ARG;   // params.rs:26-31: k > n >= l ; a2' has k-n-l cols
+  if (q < 3) return RZK_E_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return RZK_E_HIP;
+  rzk_ctx* c = new rzk_ctx();
+  c->device = device;
+  c->q = q;
+  c->N = N;
+  c->logn = N == 512 ? 9 : (N == 1024 ? 10 : 11);
+  c->n = n;
+  c->k = k;
+  c->l = l;
+  c->kappa = kappa;
+  c->b = b;
+  // params.rs:94-98, 104, 114 (usize floor square roots)
+  c->sigma = b * (11ull * kappa) * isqrt_u64((uint64_t)k * N);
+  c->commit_bound = 4 * c->sigma * isqrt_u64(N);
+  c->verify_bound = 2 * c->sigma * isqrt_u64(N);
+  if (!host::make_crt_consts((uint64_t)q, c->hT.crt)) {
+    delete c;
+    return RZK_E_UNSUPPORTED;
+  }
+  if (hipSetDevice(device) != hipSuccess) {
+    delete c;
+    return RZK_E_HIP;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+    c->num_cus = prop.multiProcessorCount;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return RZK_E_HIP;
+  }
+  c->stream = c->own_stream;
+  // twiddle tables: 3 primes x {fwd, inv} x kTableLen
+  std::vector<uint32_t> all((size_t)2 * kMaxPrimes * kTableLen);
+  for (int i = 0; i < kMaxPrimes; ++i) {
+    std::vector<uint32_t> f, v;
+    host::make_twiddles(i, f, v);
+    std::memcpy(&all[(size_t)(2 * i) * kTableLen], f.data(), sizeof(uint32_t) * kTableLen);
+    std::memcpy(&all[(size_t)(2 * i + 1) * kTableLen], v.data(), sizeof(uint32_t) * kTableLen);
+    c->hT.pc[i] = host::make_prime_consts(i, N);
+  }
+  bool okk = hipMalloc((void**)&c->d_tw, all.size() * sizeof(uint32_t)) == hipSuccess &&
+             hipMemcpy(c->d_tw, all.data(), all.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
+  for (int i = 0; i < kMaxPrimes && okk; ++i) {
+    c->hT.tw_fwd[i] = c->d_tw + (size_t)(2 * i) * kTableLen;
+    c->hT.tw_inv[i] = c->d_tw + (size_t)(2 * i + 1) * kTableLen;
+  }
+  c->hT.cap[0] = 0.0;
+  for (int np = 1; np <= kMaxPrimes; ++np) c->hT.cap[np] = host::crt_capacity(np);
+  okk = okk && hipMalloc((void**)&c->dT, sizeof(DevTables)) == hipSuccess &&
+        hipMemcpy(c->dT, &c->hT, sizeof(DevTables), hipMemcpyHostToDevice) == hipSuccess;
+  if (!okk) {
+    rzk_ctx_destroy(c);
+    return RZK_E_HIP;
+  }
+  *out = c;
+  return RZK_OK;
+}
+
+void rzk_ctx_destroy(rzk_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  drop_programs(c);
+  for (auto& ev : c->prof_events) {
+    (void)hipEventDestroy(ev.first);
+    (void)hipEventDestroy(ev.second);
+  }
+  if (c->d_key_ntt) (void)hipFree(c->d_key_ntt);
+  if (c->d_key_inf) (void)hipFree(c->d_key_inf);
+  if (c->ws.p) (void)hipFree(c->ws.p);
+  if (c->stage.p) (void)hipFree(c->stage.p);
+  if (c->dT) (void)hipFree(c->dT);
+  if (c->d_tw) (void)hipFree(c->d_tw);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int rzk_ctx_set_stream(rzk_ctx* c, void* hip_stream) {
+  if (!c) return RZK_E_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  return RZK_OK;
+}
+
+int rzk_ctx_synchronize(rzk_ctx* c) {
+  if (!c) return RZK_E_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return RZK_OK;
+}
+
+const char* rzk_last_error(const rzk_ctx* c) { return c ? c->err.c_str() : "null context"; }
+uint64_t rzk_sigma(const rzk_ctx* c) { return c ? c->sigma : 0; }
+uint64_t rzk_commit_bound(const rzk_ctx* c) { return c ? c->commit_bound : 0; }
+uint64_t rzk_verify_bound(const rzk_ctx* c) { return c ? c->verify_bound : 0; }
+
+// =================================================================================================
+// key
+// =================================================================================================
+static int key_load_impl(rzk_ctx* c, const int64_t* a_host) {
+  const uint32_t N = c->N, rows = c->n + c->l, k = c->k;
+  const size_t total = (size_t)rows * k;
+  const int64_t half = (c->q - 1) / 2;
+  c->key_class.assign(total, KC_GENERAL);
+  c->key_entry.assign(total, -1);
+  std::vector<int64_t> general;
+  std::vector<double> kinf;
+  c->n_general = 0;
+  for (size_t e = 0; e < total; ++e) {
+    const int64_t* p = a_host + e * N;
+    bool tail_zero = true;
+    int64_t mx = 0;
+    for (uint32_t j = 0; j < N; ++j) {
+      const int64_t v = p[j];
+      if (v > half || v < -half) return fail(c, RZK_E_ARG, "key coefficient outside the centred range");
+      if (j > 0 && v != 0) tail_zero = false;
+      const int64_t a = v < 0 ? -v : v;
+      if (a > mx) mx = a;
+    }
+    if (tail_zero && p[0] == 0)
+      c->key_class[e] = KC_ZERO;
+    else if (tail_zero && p[0] == 1)
+      c->key_class[e] = KC_ONE;
+    else {
+      c->key_entry[e] = (int32_t)c->n_general++;
+      general.insert(general.end(), p, p + N);
+      kinf.push_back((double)mx);
+    }
+  }
+  drop_programs(c);   // programs depend on the classification
+  if (c->d_key_ntt) HIPCHK(c, hipFree(c->d_key_ntt));
+  if (c->d_key_inf) HIPCHK(c, hipFree(c->d_key_inf));
+  c->d_key_ntt = nullptr;
+  c->d_key_inf = nullptr;
+  if (c->n_general) {
+    const size_t gbytes = general.size() * sizeof(int64_t);
+    int rc = arena_reserve(c, c->stage, gbytes);
+    if (rc != RZK_OK) return rc;
+    HIPCHK(c, hipMalloc((void**)&c->d_key_ntt, (size_t)c->n_general * kMaxPrimes * N * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_key_inf, (size_t)c->n_general * sizeof(double)));
+    HIPCHK(c, hipMemcpyAsync(c->stage.p, general.data(), gbytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_key_inf, kinf.data(), kinf.size() * sizeof(double), hipMemcpyHostToDevice,
+                             c->stream));
+    rc = check_launch(c, launch_key_transform((int)c->logn, cfg_of(c), (const int64_t*)c->stage.p, c->n_general,
+                                              c->d_key_ntt, c->dT),
+                      "key transform");
+    if (rc != RZK_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));   // `general` / `kinf` are host temporaries
+  }
+  c->key_loaded = true;
+  return RZK_OK;
+}
+
+int rzk_key_load(rzk_ctx* c, const int64_t* a_host) {
+  if (!c || !a_host) return RZK_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  return key_load_impl(c, a_host);
+}
+
+int rzk_key_load_dev(rzk_ctx* c, const int64_t* a_dev) {
+  if (!c || !a_dev) return RZK_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t total = (size_t)(c->n + c->l) * c->k * c->N;
+  std::vector<int64_t> h(total);
+  HIPCHK(c, hipMemcpyAsync(h.data(), a_dev, total * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return key_load_impl(c, h.data());
+}
+
+// =================================================================================================
+// ring / Mat primitives
+// =================================================================================================
+int rzk_polymul_batch_dev(rzk_ctx* c, const int64_t* a, const int64_t* b, int64_t* out, size_t count) {
+  if (!c || !a || !b || !out) return RZK_E_ARG;
+  return run_program(c, PG_POLYMUL, 0, {{a, 1, 1}, {b, 1, 1}, {out, 1, 1}}, nullptr, 1, count);
+}
+
+int rzk_matvec_batch_dev(rzk_ctx* c, int which, const int64_t* v, const int64_t* addend, int64_t* out, size_t B) {
+  if (!c || !v || !out || which < 0 || which > 2) return RZK_E_ARG;
+  const uint32_t rows = which == RZK_KEY_A1 ? c->n : (which == RZK_KEY_A2 ? c->l : c->n + c->l);
+  return run_program(c, PG_MATVEC, (uint32_t)which * 2 + (addend ? 1 : 0),
+                     {{v, c->k, 1}, {addend, rows, 1}, {out, rows, 1}}, nullptr, 1, B);
+}
+
+int rzk_cmul_batch_dev(rzk_ctx* c, const int64_t* m, uint32_t rows, const int64_t* p, int64_t* out, size_t B) {
+  if (!c || !m || !p || !out || rows == 0) return RZK_E_ARG;
+  if (rows > (uint32_t)kMaxRows) {
+    // more rows than one program holds: treat every row as its own batch entry sharing p
+    return run_program(c, PG_CMUL, 1, {{m, 1, 1}, {p, 1, rows}, {out, 1, 1}}, nullptr, 1, B * rows);
+  }
+  return run_program(c, PG_CMUL, rows, {{m, rows, 1}, {p, 1, 1}, {out, rows, 1}}, nullptr, 1, B);
+}
+
+int rzk_add_batch_dev(rzk_ctx* c, const int64_t* a, const int64_t* b, int64_t* out, size_t count) {
+  if (!c || !a || !b || !out) return RZK_E_ARG;
+  return check_launch(c, launch_addsub(cfg_of(c), false, a, b, out, (uint64_t)count * c->N, c->dT), "add kernel");
+}
+
+int rzk_sub_batch_dev(rzk_ctx* c, const int64_t* a, const int64_t* b, int64_t* out, size_t count) {
+  if (!c || !a || !b || !out) return RZK_E_ARG;
+  return check_launch(c, launch_addsub(cfg_of(c), true, a, b, out, (uint64_t)count * c->N, c->dT), "sub kernel");
+}
+
+int rzk_norm2_le_batch_dev(rzk_ctx* c, const int64_t* v, uint32_t rows, uint64_t bound, uint8_t* ok, size_t B) {
+  if (!c || !v || !ok || rows == 0) return RZK_E_ARG;
+  return run_norm(c, v, rows, bound, ok, B, 0, 0);
+}
+
+int rzk_eq_batch_dev(rzk_ctx* c, const int64_t* a, const int64_t* b, uint32_t rows, uint8_t* eq, size_t B) {
+  if (!c || !a || !b || !eq || rows == 0) return RZK_E_ARG;
+  return check_launch(c, launch_eq((int)c->logn, cfg_of(c), a, b, rows, eq, B), "eq kernel");
+}
+
+int rzk_ntt_forward_batch_dev(rzk_ctx* c, int prime, const uint32_t* in, uint32_t* out, size_t count) {
+  if (!c || !in || !out || prime < 0 || prime >= kMaxPrimes) return RZK_E_ARG;
+  return check_launch(c, launch_ntt((int)c->logn, false, cfg_of(c), prime, in, out, count, c->dT), "ntt forward");
+}
+
+int rzk_ntt_inverse_batch_dev(rzk_ctx* c, int prime, const uint32_t* in, uint32_t* out, size_t count) {
+  if (!c || !in || !out || prime < 0 || prime >= kMaxPrimes) return RZK_E_ARG;
+  return check_launch(c, launch_ntt((int)c->logn, true, cfg_of(c), prime, in, out, count, c->dT), "ntt inverse");
+}
+
+uint32_t rzk_ntt_prime(int prime) { return prime >= 0 && prime < kMaxPrimes ? kPrimes[prime] : 0; }
+uint32_t rzk_ntt_psi(int prime, uint32_t N) {
+  if (prime < 0 || prime >= kMaxPrimes || N == 0 || (N & (N - 1)) || N > (uint32_t)kTableLen) return 0;
+  return host::psi_for(prime, N);
+}
+uint32_t rzk_ntt_layout_index(uint32_t N, uint32_t j) {
+  if (j >= N) return 0xffffffffu;
+  const uint32_t E = N / 64;
+  const uint32_t lane = j / E, c = j % E;
+  return (c >> 2) * 256 + lane * 4 + (c & 3);
+}
+
+// =================================================================================================
+// OpenProof
+// =================================================================================================
+int rzk_open_commit_batch_dev(rzk_ctx* c, const int64_t* x, const int64_t* r, const int64_t* y, int64_t* cm,
+                              int64_t* t, uint8_t* ok, size_t B) {
+  if (!c || !x || !r || !y || !cm || !t) return RZK_E_ARG;
+  int rc = run_program(c, PG_OPEN_COMMIT, 0,
+                       {{x, c->l, 1}, {r, c->k, 1}, {y, c->k, 1}, {cm, c->n + c->l, 1}, {t, c->n, 1}}, nullptr, 1, B);
+  if (rc != RZK_OK) return rc;
+  if (ok) rc = run_norm(c, r, c->k, c->commit_bound, ok, B, 0, 0);   // params.rs:102-108
+  return rc;
+}
+
+int rzk_open_response_batch_dev(rzk_ctx* c, const int64_t* y, const int64_t* r, const int64_t* d, int64_t* z,
+                                size_t B) {
+  if (!c || !y || !r || !d || !z) return RZK_E_ARG;
+  return run_program(c, PG_RESPONSE, 1, {{d, 1, 1}, {y, c->k, 1}, {r, c->k, 1}, {z, c->k, 1}}, nullptr, 1, B);
+}
+
+int rzk_open_verify_batch_dev(rzk_ctx* c, const int64_t* z, const int64_t* t, const int64_t* cm, const int64_t* d,
+                              uint8_t* accept, size_t B) {
+  if (!c || !z || !t || !cm || !d || !accept) return RZK_E_ARG;
+  if (c->n != c->l) return fail(c, RZK_E_ARG, "c1_c2 split needs n == l (reference panics in Mat::add)");
+  int rc = run_norm(c, z, c->k, c->verify_bound, accept, B, 0, 0);   // open.rs:167-169
+  if (rc != RZK_OK) return rc;
+  return run_program(c, PG_A1_RELATION, 0, {{z, c->k, 1}, {t, c->n, 1}, {cm, c->n + c->l, 1}, {d, 1, 1}}, accept, 1, B);
+}
+
+// =================================================================================================
+// LinearProof
+// =================================================================================================
+int rzk_linear_commit_batch_dev(rzk_ctx* c, const int64_t* g, const int64_t* x, const int64_t* r, const int64_t* rp,
+                                const int64_t* y, const int64_t* yp, int64_t* cm, int64_t* cpm, int64_t* t,
+                                int64_t* tp, int64_t* u, uint8_t* ok, size_t B) {
+  if (!c || !g || !x || !r || !rp || !y || !yp || !cm || !cpm || !t || !tp || !u) return RZK_E_ARG;
+  const uint32_t n = c->n, k = c->k, l = c->l;
+  int rc = arena_reserve(c, c->ws, polys(c, 2 * B * l));
+  if (rc != RZK_OK) return rc;
+  int64_t* gx = (int64_t*)c->ws.p;
+  int64_t* a2y = gx + B * l * c->N;
+  // linear.rs:91-95: gx = x_i * g
+  rc = run_program(c, PG_CMUL, l, {{x, l, 1}, {g, 1, 1}, {gx, l, 1}}, nullptr, 1, B);
+  if (rc != RZK_OK) return rc;
+  rc = run_program(c, PG_LIN_COMMIT2, 0,
+                   {{x, l, 1}, {gx, l, 1}, {r, k, 1}, {rp, k, 1}, {y, k, 1}, {yp, k, 1}, {cm, n + l, 1},
+                    {cpm, n + l, 1}, {t, n, 1}, {tp, n, 1}, {a2y, l, 1}},
+                   nullptr, 1, B);
+  if (rc != RZK_OK) return rc;
+  rc = run_program(c, PG_LIN_U, 0, {{a2y, l, 1}, {g, 1, 1}, {yp, k, 1}, {u, l, 1}}, nullptr, 1, B);
+  if (rc != RZK_OK) return rc;
+  if (ok) {
+    rc = run_norm(c, r, k, c->commit_bound, ok, B, 0, 0);
+    if (rc != RZK_OK) return rc;
+    rc = run_norm(c, rp, k, c->commit_bound, ok, B, 2, 1);
+  }
+  return rc;
+}
+
+int rzk_linear_response_batch_dev(rzk_ctx* c, const int64_t* y, const int64_t* yp, const int64_t* r,
+                                  const int64_t* rp, const int64_t* d, int64_t* z, int64_t* zp, size_t B) {
+  if (!c || !y || !yp || !r || !rp || !d || !z || !zp) return RZK_E_ARG;
+  const uint32_t k = c->k;
+  return run_program(c, PG_RESPONSE, 2, {{d, 1, 1}, {y, k, 1}, {r, k, 1}, {z, k, 1}, {yp, k, 1}, {rp, k, 1}, {zp, k, 1}},
+                     nullptr, 1, B);
+}
+
+int rzk_linear_verify_batch_dev(rzk_ctx* c, const int64_t* z, const int64_t* zp, const int64_t* cm,
+                                const int64_t* cpm, const int64_t* g, const int64_t* t, const int64_t* tp,
+                                const int64_t* u, const int64_t* d, uint8_t* accept, size_t B) {
+  if (!c || !z || !zp || !cm || !cpm || !g || !t || !tp || !u || !d || !accept) return RZK_E_ARG;
+  if (c->n != c->l) return fail(c, RZK_E_ARG, "c1_c2 split needs n == l (reference panics in Mat::add)");
+  const uint32_t n = c->n, k = c->k, l = c->l;
+  int rc = arena_reserve(c, c->ws, polys(c, 2 * B * l));
+  if (rc != RZK_OK) return rc;
+  int64_t* w1 = (int64_t*)c->ws.p;
+  int64_t* w2 = w1 + B * l * c->N;
+  rc = run_norm(c, z, k, c->verify_bound, accept, B, 0, 0);    // linear.rs:218-220
+  if (rc != RZK_OK) return rc;
+  rc = run_norm(c, zp, k, c->verify_bound, accept, B, 1, 0);   // linear.rs:221-223
+  if (rc != RZK_OK) return rc;
+  rc = run_program(c, PG_LIN_V1, 0,
+                   {{z, k, 1}, {zp, k, 1}, {t, n, 1}, {tp, n, 1}, {cm, n + l, 1}, {cpm, n + l, 1}, {d, 1, 1}, {g, 1, 1},
+                    {w1, l, 1}, {w2, l, 1}},
+                   accept, 1, B);
+  if (rc != RZK_OK) return rc;
+  return run_program(c, PG_LIN_V2, 0, {{w1, l, 1}, {w2, l, 1}, {g, 1, 1}, {d, 1, 1}, {zp, k, 1}, {u, l, 1}}, accept, 1, B);
+}
+
+// =================================================================================================
+// SumProof
+// =================================================================================================
+int rzk_sum_commit_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* gs, const int64_t* xs, const int64_t* rs,
+                             const int64_t* rp, const int64_t* ys, const int64_t* yp, int64_t* cs, int64_t* cpm,
+                             int64_t* ts, int64_t* tp, int64_t* u, uint8_t* ok, size_t B) {
+  if (!c || V == 0 || !gs || !xs || !rs || !rp || !ys || !yp || !cs || !cpm || !ts || !tp || !u) return RZK_E_ARG;
+  const uint32_t n = c->n, k = c->k, l = c->l;
+  int rc = arena_reserve(c, c->ws, polys(c, B * l + B * V * l));
+  if (rc != RZK_OK) return rc;
+  int64_t* xp = (int64_t*)c->ws.p;
+  int64_t* w = xp + B * l * c->N;
+  // sum.rs:107-115: xp = sum_i x_i (.) g_i
+  rc = run_program(c, PG_SUM_XP, V, {{xs, V * l, 1}, {gs, V, 1}, {xp, l, 1}}, nullptr, 1, B);
+  if (rc != RZK_OK) return rc;
+  // sum.rs:116 and 151: cp = commit(xp; rp), tp = a1.yp
+  rc = run_program(c, PG_OPEN_COMMIT, 0, {{xp, l, 1}, {rp, k, 1}, {yp, k, 1}, {cpm, n + l, 1}, {tp, n, 1}}, nullptr, 1, B);
+  if (rc != RZK_OK) return rc;
+  // sum.rs:117-120 and 145-148: c_i = commit(x_i; r_i), t_i = a1.y_i — the V summands are extra batch entries
+  rc = run_program(c, PG_OPEN_COMMIT, 0, {{xs, l, 1}, {rs, k, 1}, {ys, k, 1}, {cs, n + l, 1}, {ts, n, 1}}, nullptr, 1,
+                   B * V);
+  if (rc != RZK_OK) return rc;
+  // sum.rs:154-160: u = sum_i (a2.y_i)(.)g_i - a2.yp
+  rc = run_program(c, PG_MATVEC, RZK_KEY_A2 * 2, {{ys, k, 1}, {nullptr, l, 1}, {w, l, 1}}, nullptr, 1, B * V);
+  if (rc != RZK_OK) return rc;
+  rc = run_program(c, PG_SUM_U, V, {{w, V * l, 1}, {gs, V, 1}, {yp, k, 1}, {u, l, 1}}, nullptr, 1, B);
+  if (rc != RZK_OK) return rc;
+  if (ok) {
+    rc = run_norm(c, rp, k, c->commit_bound, ok, B, 0, 0);
+    if (rc != RZK_OK) return rc;
+    rc = run_norm(c, rs, V * k, c->commit_bound, ok, B, 1, 0);
+  }
+  return rc;
+}
+
+int rzk_sum_response_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* ys, const int64_t* yp, const int64_t* rs,
+                               const int64_t* rp, const int64_t* d, int64_t* zs, int64_t* zp, size_t B) {
+  if (!c || V == 0 || !ys || !yp || !rs || !rp || !d || !zs || !zp) return RZK_E_ARG;
+  const uint32_t k = c->k;
+  // sum.rs:188-193: z_i = y_i + r_i (.) d — summands as batch entries, d shared by the V entries of a proof
+  int rc = run_program(c, PG_RESPONSE, 1, {{d, 1, V}, {ys, k, 1}, {rs, k, 1}, {zs, k, 1}}, nullptr, 1, B * V);
+  if (rc != RZK_OK) return rc;
+  // sum.rs:195-197
+  return run_program(c, PG_RESPONSE, 1, {{d, 1, 1}, {yp, k, 1}, {rp, k, 1}, {zp, k, 1}}, nullptr, 1, B);
+}
+
+int rzk_sum_verify_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* zs, const int64_t* zp, const int64_t* cs,
+                             const int64_t* cpm, const int64_t* gs, const int64_t* ts, const int64_t* tp,
+                             const int64_t* u, const int64_t* d, uint8_t* accept, size_t B) {
+  if (!c || V == 0 || !zs || !zp || !cs || !cpm || !gs || !ts || !tp || !u || !d || !accept) return RZK_E_ARG;
+  if (c->n != c->l) return fail(c, RZK_E_ARG, "c1_c2 split needs n == l (reference panics in Mat::add)");
+  const uint32_t n = c->n, k = c->k, l = c->l;
+  int rc = arena_reserve(c, c->ws, polys(c, B * V * l + B * l));
+  if (rc != RZK_OK) return rc;
+  int64_t* w1 = (int64_t*)c->ws.p;
+  int64_t* w2 = w1 + B * V * l * c->N;
+  rc = run_norm(c, zs, V * k, c->verify_bound, accept, B, 0, 0);   // sum.rs:262-268
+  if (rc != RZK_OK) return rc;
+  rc = run_norm(c, zp, k, c->verify_bound, accept, B, 1, 0);       // sum.rs:269-271
+  if (rc != RZK_OK) return rc;
+  // sum.rs:278-291: a1.z_i == t_i + c1_i (.) d for every summand (batch entries B*V, flag per proof)
+  rc = run_program(c, PG_A1_RELATION, 0, {{zs, k, 1}, {ts, n, 1}, {cs, n + l, 1}, {d, 1, V}}, accept, V, B * V);
+  if (rc != RZK_OK) return rc;
+  // sum.rs:294-298
+  rc = run_program(c, PG_A1_RELATION, 0, {{zp, k, 1}, {tp, n, 1}, {cpm, n + l, 1}, {d, 1, 1}}, accept, 1, B);
+  if (rc != RZK_OK) return rc;
+  // sum.rs:301-319
+  rc = run_program(c, PG_MATVEC, RZK_KEY_A2 * 2, {{zs, k, 1}, {nullptr, l, 1}, {w1, l, 1}}, nullptr, 1, B * V);
+  if (rc != RZK_OK) return rc;
+  rc = run_program(c, PG_SUM_W2, V, {{cs, V * (n + l), 1}, {gs, V, 1}, {cpm, n + l, 1}, {w2, l, 1}}, nullptr, 1, B);
+  if (rc != RZK_OK) return rc;
+  return run_program(c, PG_SUM_V3, V, {{w1, V * l, 1}, {gs, V, 1}, {zp, k, 1}, {w2, l, 1}, {d, 1, 1}, {u, l, 1}}, accept,
+                     1, B);
+}
+
+// =================================================================================================
+// host-pointer variants
+// =================================================================================================
+#define IN(ptr, bytes) HostBuf{(ptr), nullptr, (bytes), nullptr}
+#define OUT(ptr, bytes) HostBuf{nullptr, (ptr), (bytes), nullptr}
+#define DEV(i, T) ((T)bufs[i].dev)
+#define HOST_WRAP(call)                      \
+  do {                                       \
+    int rc_ = stage_in(c, bufs);             \
+    if (rc_ != RZK_OK) return rc_;           \
+    rc_ = (call);                            \
+    if (rc_ != RZK_OK) return rc_;           \
+    return stage_out(c, bufs);               \
+  } while (0)
+
+int rzk_polymul_batch(rzk_ctx* c, const int64_t* a, const int64_t* b, int64_t* out, size_t count) {
+  if (!c || !a || !b || !out) return RZK_E_ARG;
+  std::vector<HostBuf> bufs = {IN(a, polys(c, count)), IN(b, polys(c, count)), OUT(out, polys(c, count))};
+  HOST_WRAP(rzk_polymul_batch_dev(c, DEV(0, const int64_t*), DEV(1, const int64_t*), DEV(2, int64_t*), count));
+}
+
+int rzk_matvec_batch(rzk_ctx* c, int which, const int64_t* v, const int64_t* addend, int64_t* out, size_t B) {
+  if (!c || !v || !out || which < 0 || which > 2) return RZK_E_ARG;
+  const uint32_t rows = which == RZK_KEY_A1 ? c->n : (which == RZK_KEY_A2 ? c->l : c->n + c->l);
+  std::vector<HostBuf> bufs = {IN(v, polys(c, B * c->k)), IN(addend, addend ? polys(c, B * rows) : 0),
+                               OUT(out, polys(c, B * rows))};
+  HOST_WRAP(rzk_matvec_batch_dev(c, which, DEV(0, const int64_t*), addend ? DEV(1, const int64_t*) : nullptr,
+                                 DEV(2, int64_t*), B));
+}
+
+int rzk_cmul_batch(rzk_ctx* c, const int64_t* m, uint32_t rows, const int64_t* p, int64_t* out, size_t B) {
+  if (!c || !m || !p || !out || rows == 0) return RZK_E_ARG;
+  std::vector<HostBuf> bufs = {IN(m, polys(c, B * rows)), IN(p, polys(c, B)), OUT(out, polys(c, B * rows))};
+  HOST_WRAP(rzk_cmul_batch_dev(c, DEV(0, const int64_t*), rows, DEV(1, const int64_t*), DEV(2, int64_t*), B));
+}
+
+int rzk_add_batch(rzk_ctx* c, const int64_t* a, const int64_t* b, int64_t* out, size_t count) {
+  if (!c || !a || !b || !out) return RZK_E_ARG;
+  std::vector<HostBuf> bufs = {IN(a, polys(c, count)), IN(b, polys(c, count)), OUT(out, polys(c, count))};
+  HOST_WRAP(rzk_add_batch_dev(c, DEV(0, const int64_t*), DEV(1, const int64_t*), DEV(2, int64_t*), count));
+}
+
+int rzk_sub_batch(rzk_ctx* c, const int64_t* a, const int64_t* b, int64_t* out, size_t count) {
+  if (!c || !a || !b || !out) return RZK_E_ARG;
+  std::vector<HostBuf> bufs = {IN(a, polys(c, count)), IN(b, polys(c, count)), OUT(out, polys(c, count))};
+  HOST_WRAP(rzk_sub_batch_dev(c, DEV(0, const int64_t*), DEV(1, const int64_t*), DEV(2, int64_t*), count));
+}
+
+int rzk_norm2_le_batch(rzk_ctx* c, const int64_t* v, uint32_t rows, uint64_t bound, uint8_t* ok, size_t B) {
+  if (!c || !v || !ok || rows == 0) return RZK_E_ARG;
+  std::vector<HostBuf> bufs = {IN(v, polys(c, B * rows)), OUT(ok, B)};
+  HOST_WRAP(rzk_norm2_le_batch_dev(c, DEV(0, const int64_t*), rows, bound, DEV(1, uint8_t*), B));
+}
+
+int rzk_eq_batch(rzk_ctx* c, const int64_t* a, const int64_t* b, uint32_t rows, uint8_t* eq, size_t B) {
+  if (!c || !a || !b || !eq || rows == 0) return RZK_E_ARG;
+  std::vector<HostBuf> bufs = {IN(a, polys(c, B * rows)), IN(b, polys(c, B * rows)), OUT(eq, B)};
+  HOST_WRAP(rzk_eq_batch_dev(c, DEV(0, const int64_t*), DEV(1, const int64_t*), rows, DEV(2, uint8_t*), B));
+}
+
+int rzk_ntt_forward_batch(rzk_ctx* c, int prime, const uint32_t* in, uint32_t* out, size_t count) {
+  if (!c || !in || !out) return RZK_E_ARG;
+  const size_t bytes = count * c->N * sizeof(uint32_t);
+  std::vector<HostBuf> bufs = {IN(in, bytes), OUT(out, bytes)};
+  HOST_WRAP(rzk_ntt_forward_batch_dev(c, prime, DEV(0, const uint32_t*), DEV(1, uint32_t*), count));
+}
+
+int rzk_ntt_inverse_batch(rzk_ctx* c, int prime, const uint32_t* in, uint32_t* out, size_t count) {
+  if (!c || !in || !out) return RZK_E_ARG;
+  const size_t bytes = count * c->N * sizeof(uint32_t);
+  std::vector<HostBuf> bufs = {IN(in, bytes), OUT(out, bytes)};
+  HOST_WRAP(rzk_ntt_inverse_batch_dev(c, prime, DEV(0, const uint32_t*), DEV(1, uint32_t*), count));
+}
+
+int rzk_open_commit_batch(rzk_ctx* c, const int64_t* x, const int64_t* r, const int64_t* y, int64_t* cm, int64_t* t,
+                          uint8_t* ok, size_t B) {
+  if (!c || !x || !r || !y || !cm || !t) return RZK_E_ARG;
+  std::vector<HostBuf> bufs = {IN(x, polys(c, B * c->l)), IN(r, polys(c, B * c->k)), IN(y, polys(c, B * c->k)),
+                               OUT(cm, polys(c, B * (c->n + c->l))), OUT(t, polys(c, B * c->n)), OUT(ok, ok ? B : 0)};
+  HOST_WRAP(rzk_open_commit_batch_dev(c, DEV(0, const int64_t*), DEV(1, const int64_t*), DEV(2, const int64_t*),
+                                      DEV(3, int64_t*), DEV(4, int64_t*), ok ? DEV(5, uint8_t*) : nullptr, B));
+}
+
+int rzk_open_response_batch(rzk_ctx* c, const int64_t* y, const int64_t* r, const int64_t* d, int64_t* z, size_t B) {
+  if (!c || !y || !r || !d || !z) return RZK_E_ARG;
+  std::vector<HostBuf> bufs = {IN(y, polys(c, B * c->k)), IN(r, polys(c, B * c->k)), IN(d, polys(c, B)),
+                               OUT(z, polys(c, B * c->k))};
+  HOST_WRAP(rzk_open_response_batch_dev(c, DEV(0, const int64_t*), DEV(1, const int64_t*), DEV(2, const int64_t*),
+                                        DEV(3, int64_t*), B));
+}
+
+int rzk_open_verify_batch(rzk_ctx* c, const int64_t* z, const int64_t* t, const int64_t* cm, const int64_t* d,
+                          uint8_t* accept, size_t B) {
+  if (!c || !z || !t || !cm || !d || !accept) return RZK_E_ARG;
+  std::vector<HostBuf> bufs = {IN(z, polys(c, B * c->k)), IN(t, polys(c, B * c->n)),
+                               IN(cm, polys(c, B * (c->n + c->l))), IN(d, polys(c, B)), OUT(accept, B)};
+  HOST_WRAP(rzk_open_verify_batch_dev(c, DEV(0, const int64_t*), DEV(1, const int64_t*), DEV(2, const int64_t*),
+                                      DEV(3, const int64_t*), DEV(4, uint8_t*), B));
+}
+
+int rzk_linear_commit_batch(rzk_ctx* c, const int64_t* g, const int64_t* x, const int64_t* r, const int64_t* rp,
+                            const int64_t* y, const int64_t* yp, int64_t* cm, int64_t* cpm, int64_t* t, int64_t* tp,
+                            int64_t* u, uint8_t* ok, size_t B) {
+  if (!c || !g || !x || !r || !rp || !y || !yp || !cm || !cpm || !t || !tp || !u) return RZK_E_ARG;
+  const size_t k = c->k, n = c->n, l = c->l;
+  std::vector<HostBuf> bufs = {IN(g, polys(c, B)),          IN(x, polys(c, B * l)),        IN(r, polys(c, B * k)),
+                               IN(rp, polys(c, B * k)),     IN(y, polys(c, B * k)),        IN(yp, polys(c, B * k)),
+                               OUT(cm, polys(c, B * (n + l))), OUT(cpm, polys(c, B * (n + l))), OUT(t, polys(c, B * n)),
+                               OUT(tp, polys(c, B * n)),    OUT(u, polys(c, B * l)),       OUT(ok, ok ? B : 0)};
+  HOST_WRAP(rzk_linear_commit_batch_dev(c, DEV(0, const int64_t*), DEV(1, const int64_t*), DEV(2, const int64_t*),
+                                        DEV(3, const int64_t*), DEV(4, const int64_t*), DEV(5, const int64_t*),
+                                        DEV(6, int64_t*), DEV(7, int64_t*), DEV(8, int64_t*), DEV(9, int64_t*),
+                                        DEV(10, int64_t*), ok ? DEV(11, uint8_t*) : nullptr, B));
+}
+
+int rzk_linear_response_batch(rzk_ctx* c, const int64_t* y, const int64_t* yp, const int64_t* r, const int64_t* rp,
+                              const int64_t* d, int64_t* z, int64_t* zp, size_t B) {
+  if (!c || !y || !yp || !r || !rp || !d || !z || !zp) return RZK_E_ARG;
+  const size_t kb = polys(c, B * c->k);
+  std::vector<HostBuf> bufs = {IN(y, kb), IN(yp, kb), IN(r, kb), IN(rp, kb), IN(d, polys(c, B)), OUT(z, kb), OUT(zp, kb)};
+  HOST_WRAP(rzk_linear_response_batch_dev(c, DEV(0, const int64_t*), DEV(1, const int64_t*), DEV(2, const int64_t*),
+                                          DEV(3, const int64_t*), DEV(4, const int64_t*), DEV(5, int64_t*),
+                                          DEV(6, int64_t*), B));
+}
+
+int rzk_linear_verify_batch(rzk_ctx* c, const int64_t* z, const int64_t* zp, const int64_t* cm, const int64_t* cpm,
+                            const int64_t* g, const int64_t* t, const int64_t* tp, const int64_t* u, const int64_t* d,
+                            uint8_t* accept, size_t B) {
+  if (!c || !z || !zp || !cm || !cpm || !g || !t || !tp || !u || !d || !accept) return RZK_E_ARG;
+  const size_t k = c->k, n = c->n, l = c->l;
+  std::vector<HostBuf> bufs = {IN(z, polys(c, B * k)),   IN(zp, polys(c, B * k)), IN(cm, polys(c, B * (n + l))),
+                               IN(cpm, polys(c, B * (n + l))), IN(g, polys(c, B)), IN(t, polys(c, B * n)),
+                               IN(tp, polys(c, B * n)),  IN(u, polys(c, B * l)),  IN(d, polys(c, B)),
+                               OUT(accept, B)};
+  HOST_WRAP(rzk_linear_verify_batch_dev(c, DEV(0, const int64_t*), DEV(1, const int64_t*), DEV(2, const int64_t*),
+                                        DEV(3, const int64_t*), DEV(4, const int64_t*), DEV(5, const int64_t*),
+                                        DEV(6, const int64_t*), DEV(7, const int64_t*), DEV(8, const int64_t*),
+                                        DEV(9, uint8_t*), B));
+}
+
+int rzk_sum_commit_batch(rzk_ctx* c, uint32_t V, const int64_t* gs, const int64_t* xs, const int64_t* rs,
+                         const int64_t* rp, const int64_t* ys, const int64_t* yp, int64_t* cs, int64_t* cpm,
+                         int64_t* ts, int64_t* tp, int64_t* u, uint8_t* ok, size_t B) {
+  if (!c || V == 0 || !gs || !xs || !rs || !rp || !ys || !yp || !cs || !cpm || !ts || !tp || !u) return RZK_E_ARG;
+  const size_t k = c->k, n = c->n, l = c->l;
+  std::vector<HostBuf> bufs = {IN(gs, polys(c, B * V)),        IN(xs, polys(c, B * V * l)), IN(rs, polys(c, B * V * k)),
+                               IN(rp, polys(c, B * k)),        IN(ys, polys(c, B * V * k)), IN(yp, polys(c, B * k)),
+                               OUT(cs, polys(c, B * V * (n + l))), OUT(cpm, polys(c, B * (n + l))),
+                               OUT(ts, polys(c, B * V * n)),   OUT(tp, polys(c, B * n)),    OUT(u, polys(c, B * l)),
+                               OUT(ok, ok ? B : 0)};
+  HOST_WRAP(rzk_sum_commit_batch_dev(c, V, DEV(0, const int64_t*), DEV(1, const int64_t*), DEV(2, const int64_t*),
+                                     DEV(3, const int64_t*), DEV(4, const int64_t*), DEV(5, const int64_t*),
+                                     DEV(6, int64_t*), DEV(7, int64_t*), DEV(8, int64_t*), DEV(9, int64_t*),
+                                     DEV(10, int64_t*), ok ? DEV(11, uint8_t*) : nullptr, B));
+}
+
+int rzk_sum_response_batch(rzk_ctx* c, uint32_t V, const int64_t* ys, const int64_t* yp, const int64_t* rs,
+                           const int64_t* rp, const int64_t* d, int64_t* zs, int64_t* zp, size_t B) {
+  if (!c || V == 0 || !ys || !yp || !rs || !rp || !d || !zs || !zp) return RZK_E_ARG;
+  const size_t k = c->k;
+  std::vector<HostBuf> bufs = {IN(ys, polys(c, B * V * k)), IN(yp, polys(c, B * k)), IN(rs, polys(c, B * V * k)),
+                               IN(rp, polys(c, B * k)),     IN(d, polys(c, B)),      OUT(zs, polys(c, B * V * k)),
+                               OUT(zp, polys(c, B * k))};
+  HOST_WRAP(rzk_sum_response_batch_dev(c, V, DEV(0, const int64_t*), DEV(1, const int64_t*), DEV(2, const int64_t*),
+                                       DEV(3, const int64_t*), DEV(4, const int64_t*), DEV(5, int64_t*),
+                                       DEV(6, int64_t*), B));
+}
+
+int rzk_sum_verify_batch(rzk_ctx* c, uint32_t V, const int64_t* zs, const int64_t* zp, const int64_t* cs,
+                         const int64_t* cpm, const int64_t* gs, const int64_t* ts, const int64_t* tp, const int64_t* u,
+                         const int64_t* d, uint8_t* accept, size_t B) {
+  if (!c || V == 0 || !zs || !zp || !cs || !cpm || !gs || !ts || !tp || !u || !d || !accept) return RZK_E_ARG;
+  const size_t k = c->k, n = c->n, l = c->l;
+  std::vector<HostBuf> bufs = {IN(zs, polys(c, B * V * k)),       IN(zp, polys(c, B * k)),
+                               IN(cs, polys(c, B * V * (n + l))), IN(cpm, polys(c, B * (n + l))),
+                               IN(gs, polys(c, B * V)),           IN(ts, polys(c, B * V * n)),
+                               IN(tp, polys(c, B * n)),           IN(u, polys(c, B * l)),
+                               IN(d, polys(c, B)),                OUT(accept, B)};
+  HOST_WRAP(rzk_sum_verify_batch_dev(c, V, DEV(0, const int64_t*), DEV(1, const int64_t*), DEV(2, const int64_t*),
+                                     DEV(3, const int64_t*), DEV(4, const int64_t*), DEV(5, const int64_t*),
+                                     DEV(6, const int64_t*), DEV(7, const int64_t*), DEV(8, const int64_t*),
+                                     DEV(9, uint8_t*), B));
+}
+
+// =================================================================================================
+// instrumentation
+// =================================================================================================
+double rzk_bench_ntt_forward_dev(rzk_ctx* c, int prime, const uint32_t* in, uint32_t* out, size_t count, int iters) {
+  if (!c || !in || !out || iters <= 0 || prime < 0 || prime >= kMaxPrimes) return (double)RZK_E_ARG;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return (double)RZK_E_HIP;
+  // warm-up launch, then `iters` back-to-back launches between two events on the launch stream
+  int rc = rzk_ntt_forward_batch_dev(c, prime, in, out, count);
+  if (rc == RZK_OK && hipEventRecord(e0, c->stream) != hipSuccess) rc = RZK_E_HIP;
+  for (int i = 0; i < iters && rc == RZK_OK; ++i) rc = rzk_ntt_forward_batch_dev(c, prime, in, out, count);
+  if (rc == RZK_OK && hipEventRecord(e1, c->stream) != hipSuccess) rc = RZK_E_HIP;
+  if (rc == RZK_OK && hipEventSynchronize(e1) != hipSuccess) rc = RZK_E_HIP;
+  float ms = 0.f;
+  if (rc == RZK_OK && hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = RZK_E_HIP;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (rc != RZK_OK) return (double)rc;
+  return (double)ms * 1000.0 / iters;
+}
+
+int rzk_prof_enable(rzk_ctx* c, int on) {
+  if (!c) return RZK_E_ARG;
+  c->prof = on != 0;
+  return RZK_OK;
+}
+
+int rzk_prof_reset(rzk_ctx* c) {
+  if (!c) return RZK_E_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->prof_used = 0;
+  c->prof_us = 0.0;
+  c->prof_launches = 0;
+  return RZK_OK;
+}
+
+int rzk_prof_read(rzk_ctx* c, double* row_kernel_us, uint64_t* row_kernel_launches) {
+  if (!c) return RZK_E_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (size_t i = 0; i < c->prof_used; ++i) {
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->prof_events[i].first, c->prof_events[i].second));
+    c->prof_us += (double)ms * 1000.0;
+    c->prof_launches++;
+  }
+  c->prof_used = 0;
+  if (row_kernel_us) *row_kernel_us = c->prof_us;
+  if (row_kernel_launches) *row_kernel_launches = c->prof_launches;
+  return RZK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// rzk_dev.h — structures shared by the kernels (rzk_kernels.hip) and the C-ABI host code (rzk_api.cpp).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "rzk_core.h"
+
+namespace rzk {
+
+// Constants every kernel receives by value (kernarg -> SGPRs).
+struct DevTables {
+  const uint32_t* tw_fwd[kMaxPrimes];   // psi^{bitrev}   * R, kTableLen entries each
+  const uint32_t* tw_inv[kMaxPrimes];   // psi^{-bitrev}  * R
+  PrimeConsts pc[kMaxPrimes];
+  CrtConsts crt;
+  double cap[kMaxPrimes + 1];           // cap[np] = largest |exact result| np primes can represent
+};
+
+// ---- row programs ------------------------------------------------------------------------------------
+// Every protocol phase is a small "row program": for each proof b of the batch and each output row,
+//
+//     out_row = sum_terms sign * (KEY[entry]  (*)  V[b][src])        key entry times a per-proof polynomial
+//             + sum_terms sign * (U[b][srcA]  (*)  V[b][srcB])        product of two per-proof polynomials
+//             + sum_adds  sign *  T[b][src]                           plain additions
+//
+// evaluated by ONE wavefront: the products are accumulated in the NTT domain of as many auxiliary
+// primes as the exact integer result needs (decided per row from the operands' norms), transformed
+// back once, CRT-reconstructed, reduced to the centred representative mod q, then the additions are
+// applied.  The result is either stored (MODE_STORE) or tested against zero (MODE_ZERO, the
+// `lhs == rhs` of the verifiers, e.g. src/prove/open.rs:173).
+constexpr int kMaxOperands = 12;
+constexpr int kMaxRows = 48;
+constexpr int kMaxTerms = 640;
+constexpr int kMaxAdds = 128;
+
+enum : uint8_t { TERM_KEY = 0, TERM_VEC = 1 };
+enum : uint8_t { MODE_STORE = 0, MODE_ZERO = 1 };
+
+struct Term {
+  uint8_t kind;     // TERM_KEY: KEY[a_off] (*) operand(b_op, b_off);  TERM_VEC: (a_op,a_off) (*) (b_op,b_off)
+  int8_t sign;      // +1 / -1
+  uint8_t a_op, b_op;
+  uint16_t a_off, b_off;
+};
+struct AddTerm {
+  uint8_t op;
+  int8_t sign;
+  uint16_t off;
+};
+struct Row {
+  uint16_t term0, nterms, add0, nadds;
+  uint8_t out_op, mode;
+  uint16_t out_off;
+};
+struct Program {
+  uint32_t nrows, nterms, nadds, pad;
+  Row rows[kMaxRows];
+  Term terms[kMaxTerms];
+  AddTerm adds[kMaxAdds];
+};
+
+// Operand table of one launch: polynomial (op, off) of task-batch index b lives at
+// base[op] + ((b / div[op]) * stride[op] + off) * N.
+struct Operands {
+  int64_t* base[kMaxOperands];
+  uint32_t stride[kMaxOperands];
+  uint32_t div[kMaxOperands];
+  uint32_t flag_div;   // flags[b / flag_div]
+  uint32_t pad;
+};
+
+// ---- launchers (defined in rzk_kernels.hip) --------------------------------------------------------------------
+struct LaunchCfg {
+  void* stream;   // hipStream_t
+  int num_cus;
+};
+
+int launch_row_program(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows,
+                       const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf,
+                       const DevTables* d_T, uint8_t* d_flags, uint64_t batch);
+int launch_key_transform(int logn, const LaunchCfg& cfg, const int64_t* d_key, uint32_t entries,
+                         uint32_t* d_key_ntt, const DevTables* d_T);
+int launch_ntt(int logn, bool inverse, const LaunchCfg& cfg, int prime, const uint32_t* d_in,
+               uint32_t* d_out, uint64_t count, const DevTables* d_T);
+int launch_addsub(const LaunchCfg& cfg, bool sub, const int64_t* a, const int64_t* b, int64_t* out,
+                  uint64_t ncoef, const DevTables* d_T);
+// ok[b] = (all `rows` polys of proof b have sum c^2 < limit), limit = (bound+1)^2 given as hi:lo.
+// and_mode: 0 = overwrite ok[b], 1 = ok[b] &= result, 2 = ok[b] |= result << shift
+int launch_norm(int logn, const LaunchCfg& cfg, const int64_t* v, uint32_t rows, uint64_t limit_hi,
+                uint64_t limit_lo, uint8_t* ok, uint64_t B, int and_mode, int shift);
+int launch_eq(int logn, const LaunchCfg& cfg, const int64_t* a, const int64_t* b, uint32_t rows,
+              uint8_t* eq, uint64_t B);
+int launch_fill_u8(const LaunchCfg& cfg, uint8_t* p, uint8_t v, uint64_t n);
+
+}  // namespace rzk

@@ -1,0 +1,604 @@
+// rzk_kernels.hip — gfx950 (MI355X) kernels of the ring-zk polynomial-ring backend.
+//
+// Execution model: one 64-lane wavefront owns one polynomial-sized unit of work (one output row of
+// one proof, or one transform); workgroups are 4 independent wavefronts (no workgroup barriers),
+// each with a private LDS slab of N + N/32 words for the two transpositions of the wave NTT
+// (rzk_core.h).  Global accesses are coalesced: coefficient slabs are read/written with lane-
+// consecutive 8-byte accesses (512 B per wave instruction), NTT-domain data (resident key, transform
+// output) with 16-byte accesses (1 KiB per wave instruction).  No MFMA: the work is 32-bit integer
+// modular arithmetic (v_mad_u64_u32 / v_mul_lo_u32), bounded by HBM traffic and integer VALU rate.
+#include <hip/hip_runtime.h>
+
+#include "rzk_core.h"
+#include "rzk_dev.h"
+
+namespace rzk {
+
+// Order LDS traffic of the lanes of one wavefront (write phase -> read phase).  A wavefront issues
+// its LDS instructions in program order, so no s_barrier is needed; the fences only stop the
+// compiler from moving LDS accesses across the phase boundary.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int LOGN>
+__device__ __forceinline__ void wave_fwd(uint32_t* x, int lane, uint32_t* lds, const uint32_t* tw,
+                                         const PrimeConsts& pc) {
+  fwd_phase1<LOGN>(x, tw, pc);
+  lds_put_p1<LOGN>(x, lane, lds);
+  wave_sync();
+  lds_get_p2<LOGN>(x, lane, lds);
+  wave_sync();
+  fwd_phase2<LOGN>(x, lane, tw, pc);
+  lds_put_p2<LOGN>(x, lane, lds);
+  wave_sync();
+  lds_get_p3<LOGN>(x, lane, lds);
+  wave_sync();
+  fwd_phase3<LOGN>(x, lane, tw, pc);
+}
+
+template <int LOGN>
+__device__ __forceinline__ void wave_inv(uint32_t* x, int lane, uint32_t* lds, const uint32_t* tw,
+                                         const PrimeConsts& pc) {
+  inv_phase3<LOGN>(x, lane, tw, pc);
+  lds_put_p3<LOGN>(x, lane, lds);
+  wave_sync();
+  lds_get_p2<LOGN>(x, lane, lds);
+  wave_sync();
+  inv_phase2<LOGN>(x, lane, tw, pc);
+  lds_put_p2<LOGN>(x, lane, lds);
+  wave_sync();
+  lds_get_p1<LOGN>(x, lane, lds);
+  wave_sync();
+  inv_phase1<LOGN>(x, tw, pc);
+}
+
+// ---- wave reductions ------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    uint32_t lo = __shfl_xor((uint32_t)v, off, 64);
+    uint32_t hi = __shfl_xor((uint32_t)(v >> 32), off, 64);
+    v += ((uint64_t)hi << 32) | lo;
+  }
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    uint32_t o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+__device__ __forceinline__ const int64_t* operand_ptr(const Operands& ops, uint32_t op, uint32_t off,
+                                                       uint64_t b, int n_coef) {
+  const uint64_t poly = (b / ops.div[op]) * ops.stride[op] + off;
+  return ops.base[op] + poly * (uint64_t)n_coef;
+}
+
+// ||v||_1 and ||v||_inf of one coefficient polynomial (phase-1 / coalesced layout)
+template <int LOGN>
+__device__ __forceinline__ void poly_norms(const int64_t* __restrict__ p, int lane, double& l1,
+                                           double& linf) {
+  using G = Geo<LOGN>;
+  uint64_t s = 0;
+  uint32_t m = 0;
+#pragma unroll
+  for (int e = 0; e < G::E; ++e) {
+    const int32_t v = (int32_t)p[G::j_p1(lane, e)];
+    const uint32_t a = (uint32_t)(v < 0 ? -v : v);
+    s += a;
+    m = a > m ? a : m;
+  }
+  l1 = (double)wave_sum_u64(s);
+  linf = (double)wave_max_u32(m);
+}
+
+// =============================================================================================
+// Row-program kernel: the fused product / accumulate / reduce pipeline of every protocol phase.
+// =============================================================================================
+template <int LOGN>
+__global__ void __launch_bounds__(256)
+row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t* __restrict__ key_ntt,
+           const double* __restrict__ key_inf, const DevTables* __restrict__ Tp, uint8_t* __restrict__ flags,
+           const uint64_t batch) {
+  using G = Geo<LOGN>;
+  constexpr int E = G::E;
+  constexpr int N = G::N;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  uint32_t* lds = smem + wave * G::LDS_WORDS;
+  const DevTables& T = *Tp;
+  const uint32_t nrows = prog->nrows;
+  const uint64_t ntasks = batch * nrows;
+
+  for (uint64_t task = (uint64_t)blockIdx.x * 4 + wave; task < ntasks; task += (uint64_t)gridDim.x * 4) {
+    const uint64_t b = task / nrows;
+    const uint32_t rowi = (uint32_t)(task - b * nrows);
+    const Row row = prog->rows[rowi];
+
+    // ---- 1. how many primes does the exact integer result need?  |sum| <= sum_t ||a||_1 ||b||_inf
+    double bound = 0.0;
+#pragma unroll 1
+    for (uint32_t t = 0; t < row.nterms; ++t) {
+      const Term tm = prog->terms[row.term0 + t];
+      double l1b, infb;
+      poly_norms<LOGN>(operand_ptr(ops, tm.b_op, tm.b_off, b, N), lane, l1b, infb);
+      if (tm.kind == TERM_KEY) {
+        bound += key_inf[tm.a_off] * l1b;
+      } else {
+        double l1a, infa;
+        poly_norms<LOGN>(operand_ptr(ops, tm.a_op, tm.a_off, b, N), lane, l1a, infa);
+        const double u = l1a * infb, v = infa * l1b;
+        bound += u < v ? u : v;
+      }
+    }
+    bound *= 1.0 + 1e-9;   // the double products above are rounded; stay on the safe side
+    int np = bound <= T.cap[1] ? 1 : (bound <= T.cap[2] ? 2 : 3);
+    np = __builtin_amdgcn_readfirstlane(np);
+
+    // ---- 2. per prime: accumulate the products in the NTT domain, transform back once
+    uint32_t res0[E], res1[E], res2[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) res0[e] = res1[e] = res2[e] = 0;
+
+    if (row.nterms > 0) {
+#pragma unroll 1
+      for (int pi = np - 1; pi >= 0; --pi) {
+        const PrimeConsts pc = T.pc[pi];
+        const uint32_t* __restrict__ twf = T.tw_fwd[pi];
+        const uint32_t* __restrict__ twi = T.tw_inv[pi];
+        uint32_t acc[E];
+#pragma unroll
+        for (int c = 0; c < E; ++c) acc[c] = 0;
+#pragma unroll 1
+        for (uint32_t t = 0; t < row.nterms; ++t) {
+          const Term tm = prog->terms[row.term0 + t];
+          uint32_t x[E], xb[E];
+          const int npass = tm.kind == TERM_VEC ? 2 : 1;
+#pragma unroll 1
+          for (int pass = 0; pass < npass; ++pass) {
+            const int64_t* __restrict__ src = pass == 0 ? operand_ptr(ops, tm.b_op, tm.b_off, b, N)
+                                                        : operand_ptr(ops, tm.a_op, tm.a_off, b, N);
+#pragma unroll
+            for (int e = 0; e < E; ++e) x[e] = lift((int32_t)src[G::j_p1(lane, e)], pc);
+            wave_fwd<LOGN>(x, lane, lds, twf, pc);
+            if (pass + 1 < npass) {
+              // second operand of a vec*vec term: fold N^-1 and the Montgomery factor in here
+#pragma unroll
+              for (int c = 0; c < E; ++c)
+                xb[c] = csub(mont_lazy(x[c], pc.ninv_r2, pc.p, pc.npinv), pc.p);
+            }
+          }
+          if (tm.kind == TERM_KEY) {
+            const uint4* __restrict__ kp =
+                reinterpret_cast<const uint4*>(key_ntt + ((uint64_t)tm.a_off * kMaxPrimes + pi) * N);
+#pragma unroll
+            for (int g = 0; g < E / 4; ++g) {
+              const uint4 kv = kp[g * 64 + lane];
+              xb[4 * g + 0] = kv.x;
+              xb[4 * g + 1] = kv.y;
+              xb[4 * g + 2] = kv.z;
+              xb[4 * g + 3] = kv.w;
+            }
+          }
+          if (tm.sign >= 0) {
+#pragma unroll
+            for (int c = 0; c < E; ++c) acc[c] = mac_add(acc[c], x[c], xb[c], pc);
+          } else {
+#pragma unroll
+            for (int c = 0; c < E; ++c) acc[c] = mac_sub(acc[c], x[c], xb[c], pc);
+          }
+        }
+        wave_inv<LOGN>(acc, lane, lds, twi, pc);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          res2[e] = res1[e];
+          res1[e] = res0[e];
+          res0[e] = acc[e];
+        }
+      }
+    }
+
+    // ---- 3. CRT -> centred mod q, plain additions, store / zero test
+    int64_t s[E];
+    if (row.nterms > 0) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) s[e] = crt_center(res0[e], res1[e], res2[e], np, T.pc, T.crt);
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) s[e] = 0;
+    }
+#pragma unroll 1
+    for (uint32_t a = 0; a < row.nadds; ++a) {
+      const AddTerm ad = prog->adds[row.add0 + a];
+      const int64_t* __restrict__ src = operand_ptr(ops, ad.op, ad.off, b, N);
+      if (ad.sign >= 0) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) s[e] = center_rounds<1>(s[e] + src[G::j_p1(lane, e)], T.crt);
+      } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) s[e] = center_rounds<1>(s[e] - src[G::j_p1(lane, e)], T.crt);
+      }
+    }
+    if (row.mode == MODE_STORE) {
+      int64_t* __restrict__ dst = const_cast<int64_t*>(operand_ptr(ops, row.out_op, row.out_off, b, N));
+#pragma unroll
+      for (int e = 0; e < E; ++e) dst[G::j_p1(lane, e)] = s[e];
+    } else {
+      int nz = 0;
+#pragma unroll
+      for (int e = 0; e < E; ++e) nz |= (s[e] != 0);
+      if (__any(nz) && lane == 0) flags[b / ops.flag_div] = 0;
+    }
+  }
+}
+
+// =============================================================================================
+// Key transform: centred key entries -> NTT domain (x N^-1, Montgomery form) for all three primes
+// =============================================================================================
+template <int LOGN>
+__global__ void __launch_bounds__(256)
+key_transform_kernel(const int64_t* __restrict__ key, uint32_t entries, uint32_t* __restrict__ key_ntt,
+                     const DevTables* __restrict__ Tp) {
+  const DevTables& T = *Tp;
+  using G = Geo<LOGN>;
+  constexpr int E = G::E;
+  constexpr int N = G::N;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  uint32_t* lds = smem + wave * G::LDS_WORDS;
+  const uint32_t ntasks = entries * kMaxPrimes;
+  for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
+    const uint32_t entry = task / kMaxPrimes;
+    const int pi = task % kMaxPrimes;
+    const PrimeConsts pc = T.pc[pi];
+    const int64_t* __restrict__ src = key + (uint64_t)entry * N;
+    uint32_t x[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) x[e] = lift((int32_t)src[G::j_p1(lane, e)], pc);
+    wave_fwd<LOGN>(x, lane, lds, T.tw_fwd[pi], pc);
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(key_ntt + ((uint64_t)entry * kMaxPrimes + pi) * N);
+#pragma unroll
+    for (int g = 0; g < E / 4; ++g) {
+      uint4 v;
+      v.x = csub(mont_lazy(x[4 * g + 0], pc.ninv_r2, pc.p, pc.npinv), pc.p);
+      v.y = csub(mont_lazy(x[4 * g + 1], pc.ninv_r2, pc.p, pc.npinv), pc.p);
+      v.z = csub(mont_lazy(x[4 * g + 2], pc.ninv_r2, pc.p, pc.npinv), pc.p);
+      v.w = csub(mont_lazy(x[4 * g + 3], pc.ninv_r2, pc.p, pc.npinv), pc.p);
+      dst[g * 64 + lane] = v;
+    }
+  }
+}
+
+// =============================================================================================
+// Stand-alone batched transforms over one auxiliary prime (the "batched NTT" of the headline metric)
+// =============================================================================================
+template <int LOGN>
+__global__ void __launch_bounds__(256)
+ntt_fwd_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t count, int pi,
+               const DevTables* __restrict__ Tp) {
+  const DevTables& T = *Tp;
+  using G = Geo<LOGN>;
+  constexpr int E = G::E;
+  constexpr int N = G::N;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  uint32_t* lds = smem + wave * G::LDS_WORDS;
+  const PrimeConsts pc = T.pc[pi];
+  const uint32_t* __restrict__ tw = T.tw_fwd[pi];
+  for (uint64_t poly = (uint64_t)blockIdx.x * 4 + wave; poly < count; poly += (uint64_t)gridDim.x * 4) {
+    const uint32_t* __restrict__ src = in + poly * N;
+    uint32_t x[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) x[e] = src[G::j_p1(lane, e)];
+    wave_fwd<LOGN>(x, lane, lds, tw, pc);
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(out + poly * N);
+#pragma unroll
+    for (int g = 0; g < E / 4; ++g) {
+      uint4 v;
+      v.x = csub(csub(x[4 * g + 0], pc.twop), pc.p);
+      v.y = csub(csub(x[4 * g + 1], pc.twop), pc.p);
+      v.z = csub(csub(x[4 * g + 2], pc.twop), pc.p);
+      v.w = csub(csub(x[4 * g + 3], pc.twop), pc.p);
+      dst[g * 64 + lane] = v;
+    }
+  }
+}
+
+template <int LOGN>
+__global__ void __launch_bounds__(256)
+ntt_inv_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t count, int pi,
+               const DevTables* __restrict__ Tp) {
+  const DevTables& T = *Tp;
+  using G = Geo<LOGN>;
+  constexpr int E = G::E;
+  constexpr int N = G::N;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  uint32_t* lds = smem + wave * G::LDS_WORDS;
+  const PrimeConsts pc = T.pc[pi];
+  const uint32_t* __restrict__ tw = T.tw_inv[pi];
+  for (uint64_t poly = (uint64_t)blockIdx.x * 4 + wave; poly < count; poly += (uint64_t)gridDim.x * 4) {
+    const uint4* __restrict__ src = reinterpret_cast<const uint4*>(in + poly * N);
+    uint32_t x[E];
+#pragma unroll
+    for (int g = 0; g < E / 4; ++g) {
+      const uint4 v = src[g * 64 + lane];
+      x[4 * g + 0] = v.x;
+      x[4 * g + 1] = v.y;
+      x[4 * g + 2] = v.z;
+      x[4 * g + 3] = v.w;
+    }
+    wave_inv<LOGN>(x, lane, lds, tw, pc);
+    uint32_t* __restrict__ dst = out + poly * N;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      dst[G::j_p1(lane, e)] = csub(mont_lazy(x[e], pc.ninv_r, pc.p, pc.npinv), pc.p);
+  }
+}
+
+// =============================================================================================
+// Element-wise kernels: Mat::add / Mat::sub, norm predicate, equality
+// =============================================================================================
+__global__ void __launch_bounds__(256)
+addsub_kernel(const int64_t* a, const int64_t* b, int64_t* out, uint64_t n2, int sub,
+              const DevTables* __restrict__ Tp) {
+  // two coefficients (16 bytes) per thread and step; out may alias a or b (in-place add/sub)
+  const DevTables& T = *Tp;
+  const longlong2* a2 = reinterpret_cast<const longlong2*>(a);
+  const longlong2* b2 = reinterpret_cast<const longlong2*>(b);
+  longlong2* o2 = reinterpret_cast<longlong2*>(out);
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
+       i += (uint64_t)gridDim.x * blockDim.x) {
+    const longlong2 x = a2[i], y = b2[i];
+    longlong2 r;
+    r.x = center_rounds<1>(sub ? x.x - y.x : x.x + y.x, T.crt);
+    r.y = center_rounds<1>(sub ? x.y - y.y : x.y + y.y, T.crt);
+    o2[i] = r;
+  }
+}
+
+// One wavefront per proof: all `rows` polynomials must satisfy sum c^2 < limit (= (bound+1)^2),
+// i.e. floor(sqrt(sum c^2)) <= bound (src/polynomial.rs:60-73, src/params.rs:105-107).
+// The sum is exact: c^2 split into 32-bit halves, accumulated in two 64-bit lanes-sums.
+template <int LOGN>
+__global__ void __launch_bounds__(256)
+norm_kernel(const int64_t* __restrict__ v, uint32_t rows, uint64_t limit_hi, uint64_t limit_lo,
+            uint8_t* __restrict__ ok, uint64_t B, int and_mode, int shift) {
+  using G = Geo<LOGN>;
+  constexpr int E = G::E;
+  constexpr int N = G::N;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  for (uint64_t b = (uint64_t)blockIdx.x * 4 + wave; b < B; b += (uint64_t)gridDim.x * 4) {
+    int good = 1;
+    for (uint32_t r = 0; r < rows; ++r) {
+      const int64_t* __restrict__ p = v + (b * rows + r) * N;
+      uint64_t slo = 0, shi = 0;
+      int huge = 0;   // |c| >= 2^32 already exceeds every admissible bound (bound < 2^32)
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const int64_t c = p[G::j_p1(lane, e)];
+        const uint64_t a = c < 0 ? 0ull - (uint64_t)c : (uint64_t)c;
+        huge |= (a >> 32) != 0;
+        const uint64_t al = a & 0xffffffffu;
+        const uint64_t ll = al * al;
+        slo += ll & 0xffffffffu;
+        shi += ll >> 32;
+      }
+      slo = wave_sum_u64(slo);
+      shi = wave_sum_u64(shi);
+      // total = shi * 2^32 + slo  (shi, slo < 2^50)
+      const uint64_t t_lo32 = slo & 0xffffffffu;
+      const uint64_t mid = shi + (slo >> 32);
+      const uint64_t tot_lo = (mid << 32) | t_lo32;
+      const uint64_t tot_hi = mid >> 32;
+      const int lt = (tot_hi < limit_hi) || (tot_hi == limit_hi && tot_lo < limit_lo);
+      good &= lt && !__any(huge);
+    }
+    if (lane == 0) {
+      if (and_mode == 0)
+        ok[b] = (uint8_t)good;
+      else if (and_mode == 1)
+        ok[b] = (uint8_t)(ok[b] & good);
+      else
+        ok[b] = (uint8_t)(ok[b] | (good << shift));
+    }
+  }
+}
+
+template <int LOGN>
+__global__ void __launch_bounds__(256)
+eq_kernel(const int64_t* __restrict__ a, const int64_t* __restrict__ b, uint32_t rows,
+          uint8_t* __restrict__ eq, uint64_t B) {
+  using G = Geo<LOGN>;
+  constexpr int E = G::E;
+  constexpr int N = G::N;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  for (uint64_t p = (uint64_t)blockIdx.x * 4 + wave; p < B; p += (uint64_t)gridDim.x * 4) {
+    int ne = 0;
+    for (uint32_t r = 0; r < rows; ++r) {
+      const int64_t* __restrict__ pa = a + (p * rows + r) * N;
+      const int64_t* __restrict__ pb = b + (p * rows + r) * N;
+#pragma unroll
+      for (int e = 0; e < E; ++e) ne |= (pa[G::j_p1(lane, e)] != pb[G::j_p1(lane, e)]);
+    }
+    const int any_ne = __any(ne);
+    if (lane == 0) eq[p] = (uint8_t)(any_ne ? 0 : 1);
+  }
+}
+
+__global__ void __launch_bounds__(256) fill_u8_kernel(uint8_t* p, uint8_t v, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+
+// =============================================================================================
+// Launchers
+// =============================================================================================
+static inline unsigned grid_for(uint64_t tasks, int num_cus, int waves_per_block = 4, int blocks_per_cu = 8) {
+  uint64_t blocks = (tasks + waves_per_block - 1) / waves_per_block;
+  const uint64_t cap = (uint64_t)num_cus * blocks_per_cu;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+#define RZK_LAUNCH_CHECK()                      \
+  do {                                          \
+    hipError_t e_ = hipGetLastError();          \
+    if (e_ != hipSuccess) return (int)e_;       \
+  } while (0)
+
+template <int LOGN>
+static int launch_row_t(const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows, const Operands& ops,
+                        const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T,
+                        uint8_t* d_flags, uint64_t batch) {
+  using G = Geo<LOGN>;
+  const size_t lds = 4 * G::LDS_WORDS * sizeof(uint32_t);
+  const unsigned grid = grid_for(batch * nrows, cfg.num_cus);
+  hipLaunchKernelGGL(row_kernel<LOGN>, dim3(grid), dim3(256), lds, (hipStream_t)cfg.stream, d_prog, ops,
+                     d_key_ntt, d_key_inf, T, d_flags, batch);
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_row_program(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows,
+                       const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf,
+                       const DevTables* T, uint8_t* d_flags, uint64_t batch) {
+  if (batch == 0 || nrows == 0) return 0;
+  switch (logn) {
+    case 9: return launch_row_t<9>(cfg, d_prog, nrows, ops, d_key_ntt, d_key_inf, T, d_flags, batch);
+    case 10: return launch_row_t<10>(cfg, d_prog, nrows, ops, d_key_ntt, d_key_inf, T, d_flags, batch);
+    case 11: return launch_row_t<11>(cfg, d_prog, nrows, ops, d_key_ntt, d_key_inf, T, d_flags, batch);
+  }
+  return -1;
+}
+
+template <int LOGN>
+static int launch_key_t(const LaunchCfg& cfg, const int64_t* d_key, uint32_t entries, uint32_t* d_key_ntt,
+                        const DevTables* T) {
+  using G = Geo<LOGN>;
+  const size_t lds = 4 * G::LDS_WORDS * sizeof(uint32_t);
+  const unsigned grid = grid_for((uint64_t)entries * kMaxPrimes, cfg.num_cus);
+  hipLaunchKernelGGL(key_transform_kernel<LOGN>, dim3(grid), dim3(256), lds, (hipStream_t)cfg.stream,
+                     d_key, entries, d_key_ntt, T);
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_key_transform(int logn, const LaunchCfg& cfg, const int64_t* d_key, uint32_t entries,
+                         uint32_t* d_key_ntt, const DevTables* T) {
+  if (entries == 0) return 0;
+  switch (logn) {
+    case 9: return launch_key_t<9>(cfg, d_key, entries, d_key_ntt, T);
+    case 10: return launch_key_t<10>(cfg, d_key, entries, d_key_ntt, T);
+    case 11: return launch_key_t<11>(cfg, d_key, entries, d_key_ntt, T);
+  }
+  return -1;
+}
+
+template <int LOGN>
+static int launch_ntt_t(bool inverse, const LaunchCfg& cfg, int prime, const uint32_t* d_in, uint32_t* d_out,
+                        uint64_t count, const DevTables* T) {
+  using G = Geo<LOGN>;
+  const size_t lds = 4 * G::LDS_WORDS * sizeof(uint32_t);
+  const unsigned grid = grid_for(count, cfg.num_cus);
+  if (inverse)
+    hipLaunchKernelGGL(ntt_inv_kernel<LOGN>, dim3(grid), dim3(256), lds, (hipStream_t)cfg.stream, d_in,
+                       d_out, count, prime, T);
+  else
+    hipLaunchKernelGGL(ntt_fwd_kernel<LOGN>, dim3(grid), dim3(256), lds, (hipStream_t)cfg.stream, d_in,
+                       d_out, count, prime, T);
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ntt(int logn, bool inverse, const LaunchCfg& cfg, int prime, const uint32_t* d_in,
+               uint32_t* d_out, uint64_t count, const DevTables* T) {
+  if (count == 0) return 0;
+  switch (logn) {
+    case 9: return launch_ntt_t<9>(inverse, cfg, prime, d_in, d_out, count, T);
+    case 10: return launch_ntt_t<10>(inverse, cfg, prime, d_in, d_out, count, T);
+    case 11: return launch_ntt_t<11>(inverse, cfg, prime, d_in, d_out, count, T);
+  }
+  return -1;
+}
+
+int launch_addsub(const LaunchCfg& cfg, bool sub, const int64_t* a, const int64_t* b, int64_t* out,
+                  uint64_t ncoef, const DevTables* T) {
+  if (ncoef == 0) return 0;
+  const uint64_t n2 = ncoef / 2;   // ncoef is a multiple of N >= 512
+  uint64_t blocks = (n2 + 255) / 256;
+  const uint64_t cap = (uint64_t)cfg.num_cus * 8;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(addsub_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)cfg.stream, a, b,
+                     out, n2, sub ? 1 : 0, T);
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_norm(int logn, const LaunchCfg& cfg, const int64_t* v, uint32_t rows, uint64_t limit_hi,
+                uint64_t limit_lo, uint8_t* ok, uint64_t B, int and_mode, int shift) {
+  if (B == 0) return 0;
+  const unsigned grid = grid_for(B, cfg.num_cus);
+  switch (logn) {
+    case 9:
+      hipLaunchKernelGGL(norm_kernel<9>, dim3(grid), dim3(256), 0, (hipStream_t)cfg.stream, v, rows,
+                         limit_hi, limit_lo, ok, B, and_mode, shift);
+      break;
+    case 10:
+      hipLaunchKernelGGL(norm_kernel<10>, dim3(grid), dim3(256), 0, (hipStream_t)cfg.stream, v, rows,
+                         limit_hi, limit_lo, ok, B, and_mode, shift);
+      break;
+    case 11:
+      hipLaunchKernelGGL(norm_kernel<11>, dim3(grid), dim3(256), 0, (hipStream_t)cfg.stream, v, rows,
+                         limit_hi, limit_lo, ok, B, and_mode, shift);
+      break;
+    default: return -1;
+  }
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_eq(int logn, const LaunchCfg& cfg, const int64_t* a, const int64_t* b, uint32_t rows,
+              uint8_t* eq, uint64_t B) {
+  if (B == 0) return 0;
+  const unsigned grid = grid_for(B, cfg.num_cus);
+  switch (logn) {
+    case 9:
+      hipLaunchKernelGGL(eq_kernel<9>, dim3(grid), dim3(256), 0, (hipStream_t)cfg.stream, a, b, rows, eq, B);
+      break;
+    case 10:
+      hipLaunchKernelGGL(eq_kernel<10>, dim3(grid), dim3(256), 0, (hipStream_t)cfg.stream, a, b, rows, eq, B);
+      break;
+    case 11:
+      hipLaunchKernelGGL(eq_kernel<11>, dim3(grid), dim3(256), 0, (hipStream_t)cfg.stream, a, b, rows, eq, B);
+      break;
+    default: return -1;
+  }
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_fill_u8(const LaunchCfg& cfg, uint8_t* p, uint8_t v, uint64_t n) {
+  if (n == 0) return 0;
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(fill_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)cfg.stream, p, v, n);
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace rzk

@@ -1,0 +1,293 @@
+"""GPU parity tests: the HIP path (through the C ABI, include/rzk.h) against the CPU oracle.
+
+Bar: bit-exact (integer arithmetic).  Inputs are seeded; sizes are chosen so the schoolbook oracle
+finishes in seconds.  Full BASELINE sizes are covered by size-independent properties in
+tests/test_gpu_properties.py.  Shapes follow the reference's tests (tests/test.rs: fresh key,
+commit -> Commitment::verify -> challenge -> response -> verify) at the ring degrees the kernels
+support (512 / 1024 / 2048; the reference's N=16 cases are pinned on the oracle instead).
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from ring_zk_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+Q = O.Q_DEFAULT
+HALF = (Q - 1) // 2
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (torch.cuda.is_available() is False)")
+    return torch
+
+
+_ctx_cache = {}
+
+
+def ctx_for(N, n=1, k=3, l=1):
+    from ring_zk_amd import Context
+
+    key = (N, n, k, l)
+    if key not in _ctx_cache:
+        _ctx_cache[key] = Context(N, n, k, l)
+    return _ctx_cache[key]
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ---- transforms -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [512, 1024, 2048])
+def test_ntt_forward_inverse_vs_oracle(torch_mod, N):
+    ctx = ctx_for(N)
+    perm = ctx.ntt_layout()
+    assert sorted(perm.tolist()) == list(range(N))
+    rng = np.random.default_rng(N)
+    for prime in range(3):
+        p = ctx.ntt_prime(prime)
+        psi = ctx.ntt_psi(prime)
+        assert O.powmod(psi, N, p) == p - 1
+        x = rng.integers(0, p, (5, N), dtype=np.uint32)   # 5: not a multiple of the 4 waves per block
+        x[0, :3] = [0, p - 1, 1]
+        f = ctx.ntt_forward(prime, x)                      # host-pointer path
+        for i in range(x.shape[0]):
+            ref = O.ntt_forward(x[i], p, psi)
+            assert np.array_equal(f[i][perm], ref)
+        assert np.array_equal(ctx.ntt_inverse(prime, f), x)
+        # device-pointer path
+        xd = dev(torch_mod, x.view(np.int32))
+        fd = ctx.ntt_forward(prime, xd)
+        assert np.array_equal(fd.cpu().numpy().view(np.uint32), f)
+        assert np.array_equal(ctx.ntt_inverse(prime, fd).cpu().numpy().view(np.uint32), x)
+
+
+# ---- Polynomial::mul ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N", [512, 1024, 2048])
+def test_polymul_full_range_and_golden(torch_mod, N, golden):
+    ctx = ctx_for(N)
+    rng = np.random.default_rng(7 * N)
+    cases = [c for c in golden["extreme_products"] + golden["random_products"] if c["N"] == N]
+    a = np.array([c["a"] for c in cases] + [synth.uniform(rng, N).tolist() for _ in range(3)], dtype=np.int64)
+    b = np.array([c["b"] for c in cases] + [synth.uniform(rng, N).tolist() for _ in range(3)], dtype=np.int64)
+    out = ctx.polymul(a, b)
+    for i, c in enumerate(cases):
+        assert out[i].tolist() == c["out"], c.get("name", "random")
+    for i in range(len(cases), a.shape[0]):
+        assert np.array_equal(out[i], O.poly_mul(a[i], b[i]))
+    outd = ctx.polymul(dev(torch_mod, a), dev(torch_mod, b)).cpu().numpy()
+    assert np.array_equal(outd, out)
+
+
+def test_polymul_small_operands_pick_fewer_primes(torch_mod):
+    """Operand-norm dependent prime count: ternary x sparse (1 prime), key x ternary / gaussian (2)."""
+    N = 1024
+    ctx = ctx_for(N)
+    rng = np.random.default_rng(3)
+    r = synth.small(rng, (4, N))
+    d = synth.challenge(rng, (4,), N, 36)
+    kfull = synth.uniform(rng, (4, N))
+    y = synth.gauss(rng, (4, N), 21780)
+    for a, b in ((r, d), (d, r), (kfull, r), (kfull, y), (y, kfull), (kfull, d)):
+        out = ctx.polymul(a, b)
+        for i in range(4):
+            assert np.array_equal(out[i], O.poly_mul(a[i], b[i]))
+    z = np.zeros((1, N), dtype=np.int64)
+    assert not ctx.polymul(z, kfull[:1]).any()
+
+
+def test_empty_batch(torch_mod):
+    ctx = ctx_for(512)
+    e = np.empty((0, 512), dtype=np.int64)
+    assert ctx.polymul(e, e).shape == (0, 512)
+    assert ctx.add(e, e).shape == (0, 512)
+
+
+# ---- Mat seam ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(512, 1, 3, 1), (1024, 1, 3, 1), (512, 2, 5, 2), (2048, 1, 3, 1)])
+def test_matvec_cmul_add_sub_norm_eq(torch_mod, shape):
+    N, n, k, l = shape
+    ctx = ctx_for(N, n, k, l)
+    rng = np.random.default_rng(sum(shape))
+    A = synth.key(rng, N, n, k, l)
+    ctx.load_key(A)
+    B = 3
+    v = synth.uniform(rng, (B, k, N))
+    v[1] = synth.small(rng, (k, N))
+    for which, rows, sl in ((0, n, slice(0, n)), (1, l, slice(n, n + l)), (2, n + l, slice(0, n + l))):
+        addend = synth.uniform(rng, (B, rows, N))
+        out = ctx.matvec(which, v)
+        out_add = ctx.matvec(which, v, addend)
+        for b in range(B):
+            ref = O.mat_dot(A[sl], v[b][:, None, :])[:, 0, :]
+            assert np.array_equal(out[b], ref)
+            assert np.array_equal(out_add[b], O.mat_add(ref[:, None, :], addend[b][:, None, :])[:, 0, :])
+    m = synth.uniform(rng, (B, k, N))
+    p = synth.uniform(rng, (B, N))
+    cm = ctx.cmul(m, p)
+    for b in range(B):
+        assert np.array_equal(cm[b], O.mat_cmul(m[b][:, None, :], p[b])[:, 0, :])
+    a1, a2 = synth.uniform(rng, (B, k, N)), synth.uniform(rng, (B, k, N))
+    a1[0, 0, :4] = [HALF, -HALF, HALF, 0]
+    a2[0, 0, :4] = [HALF, -HALF, 1, 0]
+    s, df = ctx.add(a1, a2), ctx.sub(a1, a2)
+    for b in range(B):
+        assert np.array_equal(s[b], O.mat_add(a1[b][:, None], a2[b][:, None])[:, 0])
+        assert np.array_equal(df[b], O.mat_sub(a1[b][:, None], a2[b][:, None])[:, 0])
+    # norm predicate: floor(sqrt(sum c^2)) <= bound, exact at the boundary
+    y = synth.gauss(rng, (B, k, N), 1000)
+    nb = max(O.norm2(y[0, j]) for j in range(k))
+    assert ctx.norm2_le(y[:1], nb).tolist() == [1]
+    assert ctx.norm2_le(y[:1], nb - 1).tolist() == [0]
+    big = synth.uniform(rng, (2, k, N))
+    exp = [int(O.check_norm(big[i], 2 ** 32 - 1)) for i in range(2)]
+    assert ctx.norm2_le(big, 2 ** 32 - 1).tolist() == exp
+    kat = np.zeros((1, 1, N), dtype=np.int64)
+    kat[0, 0, :4] = [1, -2, 3, -4]                       # polynomial.rs:111-115: norm_2 = 5
+    assert ctx.norm2_le(kat, 5).tolist() == [1] and ctx.norm2_le(kat, 4).tolist() == [0]
+    # equality
+    e2 = a1.copy()
+    e2[1, k - 1, N - 1] ^= 1
+    assert ctx.eq(a1, e2).tolist() == [1, 0, 1]
+    # device-pointer path gives the same bytes
+    assert np.array_equal(ctx.matvec(2, dev(torch_mod, v)).cpu().numpy(), ctx.matvec(2, v))
+
+
+def test_shape_mismatch_is_an_error(torch_mod):
+    ctx = ctx_for(512)
+    a = np.zeros((2, 3, 512), dtype=np.int64)
+    b = np.zeros((2, 2, 512), dtype=np.int64)
+    with pytest.raises(ValueError):
+        ctx.add(a, b)                      # Mat::add panics (mat.rs:129-130)
+    with pytest.raises(ValueError):
+        ctx.matvec(0, b)                   # Mat::dot panics (mat.rs:103)
+    with pytest.raises(ValueError):
+        ctx.load_key(np.zeros((1, 3, 512), dtype=np.int64))
+
+
+# ---- OpenProof ----------------------------------------------------------------------------------------------------------
+def _P(ctx):
+    return O.Params(N=ctx.N, n=ctx.n, k=ctx.k, l=ctx.l, kappa=ctx.kappa, b=ctx.b)
+
+
+def test_open_golden_fixtures(torch_mod, golden):
+    for g in golden["open_big"]:
+        pr = g["params"]
+        ctx = ctx_for(pr["N"], pr["n"], pr["k"], pr["l"])
+        arr = lambda name: np.array(g[name], dtype=np.int64)
+        ctx.load_key(arr("A"))
+        c, t, ok = ctx.open_commit(arr("x")[None], arr("r")[None], arr("y")[None])
+        assert c[0].tolist() == g["c"] and t[0].tolist() == g["t"] and bool(ok[0]) == g["commit_ok"]
+        z = ctx.open_response(arr("y")[None], arr("r")[None], arr("d")[None])
+        assert z[0].tolist() == g["z"]
+        acc = ctx.open_verify(z, t, c, arr("d")[None])
+        assert bool(acc[0]) == g["accept"]
+
+
+@pytest.mark.parametrize("shape", [(512, 1, 3, 1), (1024, 1, 3, 1), (512, 2, 5, 2), (2048, 1, 3, 1)])
+def test_open_cycle_vs_oracle(torch_mod, shape):
+    N, n, k, l = shape
+    ctx = ctx_for(N, n, k, l)
+    P = _P(ctx)
+    assert (ctx.sigma, ctx.commit_bound, ctx.verify_bound) == (P.sigma, P.commit_bound, P.verify_bound)
+    rng = np.random.default_rng(11 + sum(shape))
+    A = synth.key(rng, N, n, k, l)
+    ctx.load_key(A)
+    B = 5 if N <= 1024 else 3
+    x = synth.uniform(rng, (B, l, N))
+    r = synth.small(rng, (B, k, N))
+    y = synth.gauss(rng, (B, k, N), P.sigma)
+    d = synth.challenge(rng, (B,), N, P.kappa)
+    r[1] = synth.uniform(rng, (k, N))          # breaks the commit constraint -> ok = 0
+    c, t, ok = ctx.open_commit(x, r, y)
+    z = ctx.open_response(y, r, d)
+    zt = z.copy()
+    zt[2, k - 1, 5] = O.center(int(zt[2, k - 1, 5]) + 1)      # tampered response -> reject
+    y_big = y.copy()
+    acc = ctx.open_verify(zt, t, c, d)
+    for b in range(B):
+        c_ref, t_ref, ok_ref = O.open_commit(P, A, x[b], r[b], y[b])
+        assert bool(ok[b]) == ok_ref
+        assert np.array_equal(t[b], t_ref)
+        assert np.array_equal(c[b], c_ref)
+        assert np.array_equal(z[b], O.open_response(P, y[b], r[b], d[b]))
+        assert int(acc[b]) == int(O.open_verify(P, A, zt[b], t[b], c[b], d[b]) == 1)
+    assert acc.tolist()[0] == 1 and acc.tolist()[2] == 0
+    # same call with device pointers (torch tensors): identical bytes
+    cd, td, okd = ctx.open_commit(dev(torch_mod, x), dev(torch_mod, r), dev(torch_mod, y))
+    assert np.array_equal(cd.cpu().numpy(), c) and np.array_equal(td.cpu().numpy(), t)
+    assert np.array_equal(okd.cpu().numpy(), ok)
+    accd = ctx.open_verify(dev(torch_mod, zt), td, cd, dev(torch_mod, d))
+    assert np.array_equal(accd.cpu().numpy(), acc)
+    del y_big
+
+
+# ---- LinearProof ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(512, 1, 3, 1), (1024, 1, 3, 1), (512, 2, 5, 2)])
+def test_linear_cycle_vs_oracle(torch_mod, shape):
+    N, n, k, l = shape
+    ctx = ctx_for(N, n, k, l)
+    P = _P(ctx)
+    rng = np.random.default_rng(21 + sum(shape))
+    A = synth.key(rng, N, n, k, l)
+    ctx.load_key(A)
+    B = 3
+    g = synth.uniform(rng, (B, N))
+    x = synth.uniform(rng, (B, l, N))
+    r, rp = synth.small(rng, (B, k, N)), synth.small(rng, (B, k, N))
+    y, yp = synth.gauss(rng, (B, k, N), P.sigma), synth.gauss(rng, (B, k, N), P.sigma)
+    d = synth.challenge(rng, (B,), N, P.kappa)
+    rp[2] = synth.uniform(rng, (k, N))
+    c, cp, t, tp, u, ok = ctx.linear_commit(g, x, r, rp, y, yp)
+    z, zp = ctx.linear_response(y, yp, r, rp, d)
+    zpt = zp.copy()
+    zpt[1, 0, 0] = O.center(int(zpt[1, 0, 0]) - 1)
+    acc = ctx.linear_verify(z, zpt, c, cp, g, t, tp, u, d)
+    for b in range(B):
+        ref = O.linear_commit(P, A, g[b], x[b], r[b], rp[b], y[b], yp[b])
+        for got, want, name in zip((c, cp, t, tp, u), ref[:5], ("c", "cp", "t", "tp", "u")):
+            assert np.array_equal(got[b], want), name
+        assert int(ok[b]) == ref[5]
+        zr, zpr = O.linear_response(P, y[b], yp[b], r[b], rp[b], d[b])
+        assert np.array_equal(z[b], zr) and np.array_equal(zp[b], zpr)
+        want = O.linear_verify(P, A, z[b], zpt[b], c[b], cp[b], g[b], t[b], tp[b], u[b], d[b])
+        assert int(acc[b]) == int(want == 1)
+    assert acc.tolist()[0] == 1 and acc.tolist()[1] == 0
+
+
+# ---- SumProof ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(512, 1, 3, 1, 4), (1024, 1, 3, 1, 2), (512, 2, 5, 2, 3)])
+def test_sum_cycle_vs_oracle(torch_mod, shape):
+    N, n, k, l, V = shape
+    ctx = ctx_for(N, n, k, l)
+    P = _P(ctx)
+    rng = np.random.default_rng(31 + sum(shape))
+    A = synth.key(rng, N, n, k, l)
+    ctx.load_key(A)
+    B = 2
+    gs = synth.uniform(rng, (B, V, N))
+    xs = synth.uniform(rng, (B, V, l, N))
+    rs, rp = synth.small(rng, (B, V, k, N)), synth.small(rng, (B, k, N))
+    ys, yp = synth.gauss(rng, (B, V, k, N), P.sigma), synth.gauss(rng, (B, k, N), P.sigma)
+    d = synth.challenge(rng, (B,), N, P.kappa)
+    cs, cp, ts, tp, u, ok = ctx.sum_commit(gs, xs, rs, rp, ys, yp)
+    zs, zp = ctx.sum_response(ys, yp, rs, rp, d)
+    zst = zs.copy()
+    zst[1, V - 1, k - 1, 7] = O.center(int(zst[1, V - 1, k - 1, 7]) + 2)
+    acc = ctx.sum_verify(zst, zp, cs, cp, gs, ts, tp, u, d)
+    for b in range(B):
+        ref = O.sum_commit(P, A, gs[b], xs[b], rs[b], rp[b], ys[b], yp[b])
+        for got, want, name in zip((cs, cp, ts, tp, u), ref[:5], ("cs", "cp", "ts", "tp", "u")):
+            assert np.array_equal(got[b], want), name
+        assert bool(ok[b]) == ref[5]
+        zr, zpr = O.sum_response(P, ys[b], yp[b], rs[b], rp[b], d[b])
+        assert np.array_equal(zs[b], zr) and np.array_equal(zp[b], zpr)
+        want = O.sum_verify(P, A, zst[b], zp[b], cs[b], cp[b], gs[b], ts[b], tp[b], u[b], d[b])
+        assert int(acc[b]) == int(want == 1)
+    assert acc.tolist() == [1, 0]

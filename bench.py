@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the ring-zk MI355X backend.
+
+Metric (BASELINE.json): proofs/sec for the full OpenProof cycle commit -> challenge -> response ->
+verify at N = 1024, (n,k,l) = (1,3,1), batch = 4096 independent proofs per GPU, plus the achieved
+HBM GB/s of the kernels against the chip's roofline.
+
+A "step" is one pass of the hot path over one batch: rzk_open_commit_batch_dev,
+rzk_open_response_batch_dev, rzk_open_verify_batch_dev on inputs already resident in HBM.  The
+challenge d is pre-sampled like every other random input (the reference samples it with the host RNG
+and does no ring arithmetic in generate_challenge — src/prove/open.rs:143-158).
+
+  python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL only for the
+barrier / result reduction: proofs are independent, the batch is simply split, weak scaling).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--N", type=int, default=1024)
+    ap.add_argument("--batch", type=int, default=4096, help="proofs per GPU and step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target length of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(N, n, k, l, seconds):
+    """CPU restatement (oracle, schoolbook multiply, literal Mat::dot) timed on the host cores."""
+    import numpy as np
+
+    from oracle import oracle as O
+    from ring_zk_amd import synth
+
+    P = O.Params(N=N, n=n, k=k, l=l)
+    threads = O.hw_threads()
+    rng = np.random.default_rng(99)
+    A = synth.key(rng, N, n, k, l)
+
+    def sample(B):
+        x = synth.uniform(rng, (B, l, N))
+        r = synth.small(rng, (B, k, N))
+        y = synth.gauss(rng, (B, k, N), P.sigma)
+        d = synth.challenge(rng, (B,), N, P.kappa)
+        t0 = time.perf_counter()
+        acc = O.open_cycle_batch(P, A, x, r, y, d, threads)
+        dt = time.perf_counter() - t0
+        assert acc == B, f"CPU baseline: {acc}/{B} proofs accepted"
+        return dt
+
+    probe = max(threads, 8)
+    dt = sample(probe)
+    rate = probe / dt
+    B = int(max(probe, min(rate * seconds, 65536)))
+    B -= B % threads or 0
+    B = max(B, threads)
+    dt = sample(B)
+    return {
+        "value": B / dt,
+        "unit": "proofs/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{B} OpenProof cycles (commit+response+verify), N={N}, (n,k,l)=({n},{k},{l}), "
+                  f"schoolbook CPU restatement (oracle/rzk_oracle.c), OpenMP over proofs, {dt:.1f} s",
+    }
+
+
+def main():
+    args = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from ring_zk_amd import Context, synth
+
+    N, n, k, l = args.N, 1, 3, 1
+    B = args.batch
+    dev = torch.device("cuda", local_rank)
+    ctx = Context(N, n, k, l, device=local_rank)
+    sig = ctx.sigma
+
+    # ---- synthetic inputs, generated directly in HBM; same key on every rank, different proofs per rank
+    gk = torch.Generator(device=dev)
+    gk.manual_seed(1234)
+    A = synth.t_key(gk, N, n, k, l, dev)
+    ctx.load_key(A)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1000 + rank)
+    x = synth.t_uniform(g, (B, l, N), dev)
+    r = synth.t_small(g, (B, k, N), dev)
+    y = synth.t_gauss(g, (B, k, N), dev, sig)
+    d = synth.t_challenge(g, B, N, ctx.kappa, dev)
+    torch.cuda.synchronize()
+
+    def step():
+        c, t, ok = ctx.open_commit(x, r, y)
+        z = ctx.open_response(y, r, d)
+        acc = ctx.open_verify(z, t, c, d)
+        return ok, acc
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ok, acc = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ok, acc = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    accepted = int(acc.sum().item())
+    ok_cnt = int(ok.sum().item())
+    assert accepted == B and ok_cnt == B, f"rank {rank}: {accepted}/{B} accepted, {ok_cnt}/{B} commit-ok"
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tot_acc = torch.tensor([accepted], dtype=torch.int64, device=dev)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot_acc, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    proofs = B * world * args.steps
+    value = proofs / elapsed
+
+    # ---- per-kernel durations with HIP events on the launch stream (separate, untimed pass)
+    roofline = None
+    ntt = None
+    if rank == 0:
+        psteps = max(3, min(args.steps, 10))
+        ctx.prof_enable(True)
+        ctx.prof_reset()
+        for _ in range(psteps):
+            step()
+        us, launches = ctx.prof_read()
+        ctx.prof_enable(False)
+        avg_us = us / max(launches, 1)
+        # algorithmic bytes of one OpenProof cycle at the boundary, key resident:
+        # commit 7 in + 3 out, response 7 in + 3 out, verify 6 in = 26 polynomials of 8*N bytes
+        cycle_bytes = 26 * 8 * N * B
+        per_launch = cycle_bytes / 3.0          # three row-kernel launches per cycle
+        achieved = per_launch / (avg_us * 1e-6) / 1e9
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_row_kernel.json")
+        if os.path.exists(pmc_path):
+            try:
+                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {
+            "kernel": "row_kernel<10> (open commit / response / verify row programs)",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic,
+            "avg_launch_us": avg_us,
+            "launches_timed": int(launches),
+            "algorithmic_bytes_per_launch": per_launch,
+        }
+        # stand-alone batched forward NTT (one residue polynomial = 2*N*4 algorithmic bytes)
+        cnt = 4 * 4096
+        xin = torch.randint(0, ctx.ntt_prime(0), (cnt, N), dtype=torch.int32, device=dev)
+        xout = torch.empty_like(xin)
+        ntt_us = ctx.bench_ntt_forward(0, xin, xout, 20)
+        ntt_gbs = cnt * 2 * N * 4 / (ntt_us * 1e-6) / 1e9
+        ntt = {"kernel": "ntt_fwd_kernel<10>", "polys": cnt, "avg_launch_us": ntt_us, "achieved": ntt_gbs,
+               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ntt_gbs / HBM_PEAK_GBS}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(N, n, k, l, args.cpu_seconds)
+
+    if rank == 0:
+        out = {
+            "metric": "proofs/sec (commit+challenge+response+verify), N=1024, batch=4096; NTT GB/s vs HBM peak",
+            "value": value,
+            "unit": "proofs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 residues of three 30-bit primes (int64 coefficients at the boundary)",
+            "data": "synthetic",
+            "config": {
+                "workload": f"OpenProof cycle, N={N}, (n,k,l)=({n},{k},{l}), kappa=36, batch={B} proofs per GPU",
+                "challenge": "pre-sampled (host RNG is outside the path)",
+                "parallelism": f"batch split over {world} GPU(s), no data-path collective",
+                "accepted": int(tot_acc.item()),
+            },
+            "roofline": roofline,
+            "ntt_roofline": ntt,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -53,9 +53,12 @@ typedef struct rzk_ctx rzk_ctx;
 int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k, uint32_t l,
                    uint32_t kappa, uint64_t b, int device);
 void rzk_ctx_destroy(rzk_ctx* ctx);
-/* Run on a caller-owned hipStream_t (e.g. PyTorch's current stream); NULL restores the own stream. */
+/* Run on a caller-owned hipStream_t (e.g. PyTorch's current stream); NULL selects HIP's default
+ * (null) stream.  rzk_ctx_use_own_stream goes back to the private stream created with the context. */
 int rzk_ctx_set_stream(rzk_ctx* ctx, void* hip_stream);
+int rzk_ctx_use_own_stream(rzk_ctx* ctx);
 int rzk_ctx_synchronize(rzk_ctx* ctx);
+/* Message of the last failure on this context; with ctx == NULL, of the last failed rzk_ctx_create. */
 const char* rzk_last_error(const rzk_ctx* ctx);
 /* sigma, 4*sigma*floor(sqrt N), 2*sigma*floor(sqrt N)   (src/params.rs:94-98,104,114) */
 uint64_t rzk_sigma(const rzk_ctx* ctx);

@@ -25,6 +25,7 @@ SIGNATURES = {
                                  C.c_uint32, C.c_uint64, C.c_int]),
     "rzk_ctx_destroy": (None, [_CTX]),
     "rzk_ctx_set_stream": (C.c_int, [_CTX, C.c_void_p]),
+    "rzk_ctx_use_own_stream": (C.c_int, [_CTX]),
     "rzk_ctx_synchronize": (C.c_int, [_CTX]),
     "rzk_last_error": (C.c_char_p, [_CTX]),
     "rzk_sigma": (C.c_uint64, [_CTX]),
@@ -71,6 +72,12 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{SO} is missing: build it with `python -m ring_zk_amd.build` (hipcc, gfx950). "
                 "The ring-zk MI355X backend has no CPU fallback.")
+        # PyTorch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Device memory and streams
+        # are shared with torch, so torch's HIP runtime must be the one this process uses: load it first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(SO)
         for name, (res, args) in SIGNATURES.items():
             f = getattr(L, name)  # AttributeError if the library does not export a declared symbol

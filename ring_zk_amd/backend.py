@@ -39,7 +39,7 @@ class Context:
         h = C.c_void_p()
         st = self._L.rzk_ctx_create(C.byref(h), q, N, n, k, l, kappa, b, device)
         if st != 0:
-            raise RzkError(st, "rzk_ctx_create failed (no usable HIP device, or unsupported N / q / shape)")
+            raise RzkError(st, "rzk_ctx_create: " + self._L.rzk_last_error(None).decode())
         self._h = h
         self._stream = None
         self.half = (q - 1) // 2
@@ -78,7 +78,7 @@ class Context:
     def _bind_torch_stream(self):
         import torch
 
-        s = torch.cuda.current_stream(self.device).cuda_stream
+        s = torch.cuda.current_stream(self.device).cuda_stream   # 0 = HIP's default stream
         if s != self._stream:
             self._check(self._L.rzk_ctx_set_stream(self._h, C.c_void_p(s)))
             self._stream = s

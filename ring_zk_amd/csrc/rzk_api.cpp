@@ -93,6 +93,13 @@ namespace {
     }                                                                                            \
   } while (0)
 
+std::string g_create_err;   // last rzk_ctx_create failure (no context exists yet to hold it)
+
+int create_fail(int code, const std::string& msg) {
+  g_create_err = msg;
+  return code;
+}
+
 int fail(rzk_ctx* c, int code, const char* msg) {
   if (c) c->err = msg;
   return code;
@@ -477,11 +484,14 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
                    uint64_t b, int device) {
   if (!out) return RZK_E_ARG;
   *out = nullptr;
-  if (N != 512 && N != 1024 && N != 2048) return RZK_E_UNSUPPORTED;
-  if (n < 1 || l < 1 || k <= n || n + l > k) return RZK_E_ARG;   // params.rs:26-31: k > n >= l ; a2' has k-n-l cols
-  if (q < 3) return RZK_E_ARG;
+  if (N != 512 && N != 1024 && N != 2048) return create_fail(RZK_E_UNSUPPORTED, "ring degree must be 512, 1024 or 2048");
+  if (n < 1 || l < 1 || k <= n || n + l > k)   // params.rs:26-31: k > n >= l ; a2' has k-n-l cols
+    return create_fail(RZK_E_ARG, "need k > n >= 1, l >= 1, n + l <= k");
+  if (q < 3) return create_fail(RZK_E_ARG, "bad modulus");
   int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return RZK_E_HIP;
+  hipError_t de = hipGetDeviceCount(&ndev);
+  if (de != hipSuccess) return create_fail(RZK_E_HIP, std::string("hipGetDeviceCount: ") + hipGetErrorString(de));
+  if (ndev <= 0 || device < 0 || device >= ndev) return create_fail(RZK_E_HIP, "no such HIP device");
   rzk_ctx* c = new rzk_ctx();
   c->device = device;
   c->q = q;
@@ -498,18 +508,18 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
   c->verify_bound = 2 * c->sigma * isqrt_u64(N);
   if (!host::make_crt_consts((uint64_t)q, c->hT.crt)) {
     delete c;
-    return RZK_E_UNSUPPORTED;
+    return create_fail(RZK_E_UNSUPPORTED, "modulus must be odd and below 4 * the smallest auxiliary prime");
   }
-  if (hipSetDevice(device) != hipSuccess) {
+  if ((de = hipSetDevice(device)) != hipSuccess) {
     delete c;
-    return RZK_E_HIP;
+    return create_fail(RZK_E_HIP, std::string("hipSetDevice: ") + hipGetErrorString(de));
   }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
     c->num_cus = prop.multiProcessorCount;
-  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+  if ((de = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking)) != hipSuccess) {
     delete c;
-    return RZK_E_HIP;
+    return create_fail(RZK_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(de));
   }
   c->stream = c->own_stream;
   // twiddle tables: 3 primes x {fwd, inv} x kTableLen
@@ -533,7 +543,7 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
         hipMemcpy(c->dT, &c->hT, sizeof(DevTables), hipMemcpyHostToDevice) == hipSuccess;
   if (!okk) {
     rzk_ctx_destroy(c);
-    return RZK_E_HIP;
+    return create_fail(RZK_E_HIP, std::string("table upload: ") + hipGetErrorString(hipGetLastError()));
   }
   *out = c;
   return RZK_OK;
@@ -561,7 +571,14 @@ void rzk_ctx_destroy(rzk_ctx* c) {
 int rzk_ctx_set_stream(rzk_ctx* c, void* hip_stream) {
   if (!c) return RZK_E_ARG;
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+  c->stream = (hipStream_t)hip_stream;   // NULL = HIP's default stream
+  return RZK_OK;
+}
+
+int rzk_ctx_use_own_stream(rzk_ctx* c) {
+  if (!c) return RZK_E_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->stream = c->own_stream;
   return RZK_OK;
 }
 
@@ -571,7 +588,7 @@ int rzk_ctx_synchronize(rzk_ctx* c) {
   return RZK_OK;
 }
 
-const char* rzk_last_error(const rzk_ctx* c) { return c ? c->err.c_str() : "null context"; }
+const char* rzk_last_error(const rzk_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 uint64_t rzk_sigma(const rzk_ctx* c) { return c ? c->sigma : 0; }
 uint64_t rzk_commit_bound(const rzk_ctx* c) { return c ? c->commit_bound : 0; }
 uint64_t rzk_verify_bound(const rzk_ctx* c) { return c ? c->verify_bound : 0; }

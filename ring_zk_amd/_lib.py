@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "librzk_hip.so")
+SO = os.environ.get("RZK_LIB", os.path.join(HERE, "librzk_hip.so"))  # RZK_LIB: tuning variants (tools/)
 
 RZK_OK, RZK_E_ARG, RZK_E_HIP, RZK_E_STATE, RZK_E_UNSUPPORTED = 0, -1, -2, -3, -4
 KEY_A1, KEY_A2, KEY_A = 0, 1, 2

@@ -28,15 +28,17 @@ def needs_build() -> bool:
     return os.path.getmtime(SO) < max(os.path.getmtime(d) for d in deps)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def build_library(force: bool = False, verbose: bool = False, out: str = SO, defines=()) -> str:
+    """`out` / `defines` build tuning variants next to the default library (used by tools/ only)."""
+    if out == SO and not force and not needs_build():
         return SO
-    cmd = [_hipcc(), "-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-shared", "-o", SO]
+    cmd = [_hipcc(), "-O3", f"--offload-arch={ARCH}", "-std=c++17", "-fPIC", "-shared", "-o", out]
+    cmd += [f"-D{d}" for d in defines]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return SO
+    return out
 
 
 if __name__ == "__main__":

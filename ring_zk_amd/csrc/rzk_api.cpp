@@ -43,6 +43,7 @@ enum ProgId : int {
 struct DevProg {
   Program* d = nullptr;
   uint32_t nrows = 0;
+  bool has_vec = false;
 };
 
 struct Arena {   // grow-only device buffer
@@ -367,6 +368,7 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
   HIPCHK(c, hipMemcpyAsync(dp.d, &pb.p, sizeof(Program), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));   // pb.p is a stack object; one-off per (program, shape)
   dp.nrows = pb.p.nrows;
+  for (uint32_t t = 0; t < pb.p.nterms; ++t) dp.has_vec = dp.has_vec || pb.p.terms[t].kind == TERM_VEC;
   c->progs[{id, var}] = dp;
   out = dp;
   return RZK_OK;
@@ -381,11 +383,12 @@ void drop_programs(rzk_ctx* c) {
 struct OpSpec {
   const int64_t* base;
   uint32_t stride;
-  uint32_t div;
+  uint32_t outer;   // 0: indexed by the task batch index; otherwise by the proof index b / group
 };
 
+// `group` > 1: the batch is B*group (proof, summand) pairs; operands with outer != 0 and the flags are per proof
 int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& specs, uint8_t* flags,
-                uint32_t flag_div, uint64_t batch) {
+                uint32_t group, uint64_t batch) {
   DevProg dp;
   int rc = get_program(c, id, var, dp);
   if (rc != RZK_OK) return rc;
@@ -394,10 +397,9 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
   for (size_t i = 0; i < specs.size(); ++i) {
     ops.base[i] = const_cast<int64_t*>(specs[i].base);
     ops.stride[i] = specs[i].stride;
-    ops.div[i] = specs[i].div ? specs[i].div : 1;
+    ops.outer[i] = specs[i].outer ? 1 : 0;
   }
-  for (size_t i = specs.size(); i < (size_t)kMaxOperands; ++i) ops.div[i] = 1;
-  ops.flag_div = flag_div ? flag_div : 1;
+  ops.group = group ? group : 1;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->prof) {
     if (c->prof_used == c->prof_events.size()) {
@@ -411,10 +413,11 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
     c->prof_used++;
     HIPCHK(c, hipEventRecord(e0, c->stream));
   }
-  int lrc = launch_row_program((int)c->logn, cfg_of(c), dp.d, dp.nrows, ops, c->d_key_ntt, c->d_key_inf,
-                               c->dT, flags, batch);
+  int lrc = launch_row_program((int)c->logn, cfg_of(c), dp.d, dp.nrows, dp.has_vec, ops, c->d_key_ntt,
+                               c->d_key_inf, c->dT, c->d_tw, flags, batch);
+  if (lrc == -2) return fail(c, RZK_E_UNSUPPORTED, "batch * rows must stay below 2^32");
   if (lrc != 0) {
-    c->err = std::string("row kernel launch: ") + hipGetErrorString((hipError_t)lrc);
+    c->err = std::string("row kernel launch: ") + (lrc > 0 ? hipGetErrorString((hipError_t)lrc) : "bad ring degree");
     return RZK_E_HIP;
   }
   if (c->prof) HIPCHK(c, hipEventRecord(e1, c->stream));
@@ -533,10 +536,6 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
   }
   bool okk = hipMalloc((void**)&c->d_tw, all.size() * sizeof(uint32_t)) == hipSuccess &&
              hipMemcpy(c->d_tw, all.data(), all.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
-  for (int i = 0; i < kMaxPrimes && okk; ++i) {
-    c->hT.tw_fwd[i] = c->d_tw + (size_t)(2 * i) * kTableLen;
-    c->hT.tw_inv[i] = c->d_tw + (size_t)(2 * i + 1) * kTableLen;
-  }
   c->hT.cap[0] = 0.0;
   for (int np = 1; np <= kMaxPrimes; ++np) c->hT.cap[np] = host::crt_capacity(np);
   okk = okk && hipMalloc((void**)&c->dT, sizeof(DevTables)) == hipSuccess &&
@@ -641,7 +640,7 @@ static int key_load_impl(rzk_ctx* c, const int64_t* a_host) {
     HIPCHK(c, hipMemcpyAsync(c->d_key_inf, kinf.data(), kinf.size() * sizeof(double), hipMemcpyHostToDevice,
                              c->stream));
     rc = check_launch(c, launch_key_transform((int)c->logn, cfg_of(c), (const int64_t*)c->stage.p, c->n_general,
-                                              c->d_key_ntt, c->dT),
+                                              c->d_key_ntt, c->dT, c->d_tw),
                       "key transform");
     if (rc != RZK_OK) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));   // `general` / `kinf` are host temporaries
@@ -671,23 +670,23 @@ int rzk_key_load_dev(rzk_ctx* c, const int64_t* a_dev) {
 // =================================================================================================
 int rzk_polymul_batch_dev(rzk_ctx* c, const int64_t* a, const int64_t* b, int64_t* out, size_t count) {
   if (!c || !a || !b || !out) return RZK_E_ARG;
-  return run_program(c, PG_POLYMUL, 0, {{a, 1, 1}, {b, 1, 1}, {out, 1, 1}}, nullptr, 1, count);
+  return run_program(c, PG_POLYMUL, 0, {{a, 1, 0}, {b, 1, 0}, {out, 1, 0}}, nullptr, 1, count);
 }
 
 int rzk_matvec_batch_dev(rzk_ctx* c, int which, const int64_t* v, const int64_t* addend, int64_t* out, size_t B) {
   if (!c || !v || !out || which < 0 || which > 2) return RZK_E_ARG;
   const uint32_t rows = which == RZK_KEY_A1 ? c->n : (which == RZK_KEY_A2 ? c->l : c->n + c->l);
   return run_program(c, PG_MATVEC, (uint32_t)which * 2 + (addend ? 1 : 0),
-                     {{v, c->k, 1}, {addend, rows, 1}, {out, rows, 1}}, nullptr, 1, B);
+                     {{v, c->k, 0}, {addend, rows, 0}, {out, rows, 0}}, nullptr, 1, B);
 }
 
 int rzk_cmul_batch_dev(rzk_ctx* c, const int64_t* m, uint32_t rows, const int64_t* p, int64_t* out, size_t B) {
   if (!c || !m || !p || !out || rows == 0) return RZK_E_ARG;
   if (rows > (uint32_t)kMaxRows) {
     // more rows than one program holds: treat every row as its own batch entry sharing p
-    return run_program(c, PG_CMUL, 1, {{m, 1, 1}, {p, 1, rows}, {out, 1, 1}}, nullptr, 1, B * rows);
+    return run_program(c, PG_CMUL, 1, {{m, 1, 0}, {p, 1, 1}, {out, 1, 0}}, nullptr, rows, B * rows);
   }
-  return run_program(c, PG_CMUL, rows, {{m, rows, 1}, {p, 1, 1}, {out, rows, 1}}, nullptr, 1, B);
+  return run_program(c, PG_CMUL, rows, {{m, rows, 0}, {p, 1, 0}, {out, rows, 0}}, nullptr, 1, B);
 }
 
 int rzk_add_batch_dev(rzk_ctx* c, const int64_t* a, const int64_t* b, int64_t* out, size_t count) {
@@ -712,12 +711,12 @@ int rzk_eq_batch_dev(rzk_ctx* c, const int64_t* a, const int64_t* b, uint32_t ro
 
 int rzk_ntt_forward_batch_dev(rzk_ctx* c, int prime, const uint32_t* in, uint32_t* out, size_t count) {
   if (!c || !in || !out || prime < 0 || prime >= kMaxPrimes) return RZK_E_ARG;
-  return check_launch(c, launch_ntt((int)c->logn, false, cfg_of(c), prime, in, out, count, c->dT), "ntt forward");
+  return check_launch(c, launch_ntt((int)c->logn, false, cfg_of(c), prime, in, out, count, c->dT, c->d_tw), "ntt forward");
 }
 
 int rzk_ntt_inverse_batch_dev(rzk_ctx* c, int prime, const uint32_t* in, uint32_t* out, size_t count) {
   if (!c || !in || !out || prime < 0 || prime >= kMaxPrimes) return RZK_E_ARG;
-  return check_launch(c, launch_ntt((int)c->logn, true, cfg_of(c), prime, in, out, count, c->dT), "ntt inverse");
+  return check_launch(c, launch_ntt((int)c->logn, true, cfg_of(c), prime, in, out, count, c->dT, c->d_tw), "ntt inverse");
 }
 
 uint32_t rzk_ntt_prime(int prime) { return prime >= 0 && prime < kMaxPrimes ? kPrimes[prime] : 0; }
@@ -739,7 +738,7 @@ int rzk_open_commit_batch_dev(rzk_ctx* c, const int64_t* x, const int64_t* r, co
                               int64_t* t, uint8_t* ok, size_t B) {
   if (!c || !x || !r || !y || !cm || !t) return RZK_E_ARG;
   int rc = run_program(c, PG_OPEN_COMMIT, 0,
-                       {{x, c->l, 1}, {r, c->k, 1}, {y, c->k, 1}, {cm, c->n + c->l, 1}, {t, c->n, 1}}, nullptr, 1, B);
+                       {{x, c->l, 0}, {r, c->k, 0}, {y, c->k, 0}, {cm, c->n + c->l, 0}, {t, c->n, 0}}, nullptr, 1, B);
   if (rc != RZK_OK) return rc;
   if (ok) rc = run_norm(c, r, c->k, c->commit_bound, ok, B, 0, 0);   // params.rs:102-108
   return rc;
@@ -748,7 +747,7 @@ int rzk_open_commit_batch_dev(rzk_ctx* c, const int64_t* x, const int64_t* r, co
 int rzk_open_response_batch_dev(rzk_ctx* c, const int64_t* y, const int64_t* r, const int64_t* d, int64_t* z,
                                 size_t B) {
   if (!c || !y || !r || !d || !z) return RZK_E_ARG;
-  return run_program(c, PG_RESPONSE, 1, {{d, 1, 1}, {y, c->k, 1}, {r, c->k, 1}, {z, c->k, 1}}, nullptr, 1, B);
+  return run_program(c, PG_RESPONSE, 1, {{d, 1, 0}, {y, c->k, 0}, {r, c->k, 0}, {z, c->k, 0}}, nullptr, 1, B);
 }
 
 int rzk_open_verify_batch_dev(rzk_ctx* c, const int64_t* z, const int64_t* t, const int64_t* cm, const int64_t* d,
@@ -757,7 +756,7 @@ int rzk_open_verify_batch_dev(rzk_ctx* c, const int64_t* z, const int64_t* t, co
   if (c->n != c->l) return fail(c, RZK_E_ARG, "c1_c2 split needs n == l (reference panics in Mat::add)");
   int rc = run_norm(c, z, c->k, c->verify_bound, accept, B, 0, 0);   // open.rs:167-169
   if (rc != RZK_OK) return rc;
-  return run_program(c, PG_A1_RELATION, 0, {{z, c->k, 1}, {t, c->n, 1}, {cm, c->n + c->l, 1}, {d, 1, 1}}, accept, 1, B);
+  return run_program(c, PG_A1_RELATION, 0, {{z, c->k, 0}, {t, c->n, 0}, {cm, c->n + c->l, 0}, {d, 1, 0}}, accept, 1, B);
 }
 
 // =================================================================================================
@@ -773,14 +772,14 @@ int rzk_linear_commit_batch_dev(rzk_ctx* c, const int64_t* g, const int64_t* x, 
   int64_t* gx = (int64_t*)c->ws.p;
   int64_t* a2y = gx + B * l * c->N;
   // linear.rs:91-95: gx = x_i * g
-  rc = run_program(c, PG_CMUL, l, {{x, l, 1}, {g, 1, 1}, {gx, l, 1}}, nullptr, 1, B);
+  rc = run_program(c, PG_CMUL, l, {{x, l, 0}, {g, 1, 0}, {gx, l, 0}}, nullptr, 1, B);
   if (rc != RZK_OK) return rc;
   rc = run_program(c, PG_LIN_COMMIT2, 0,
-                   {{x, l, 1}, {gx, l, 1}, {r, k, 1}, {rp, k, 1}, {y, k, 1}, {yp, k, 1}, {cm, n + l, 1},
-                    {cpm, n + l, 1}, {t, n, 1}, {tp, n, 1}, {a2y, l, 1}},
+                   {{x, l, 0}, {gx, l, 0}, {r, k, 0}, {rp, k, 0}, {y, k, 0}, {yp, k, 0}, {cm, n + l, 0},
+                    {cpm, n + l, 0}, {t, n, 0}, {tp, n, 0}, {a2y, l, 0}},
                    nullptr, 1, B);
   if (rc != RZK_OK) return rc;
-  rc = run_program(c, PG_LIN_U, 0, {{a2y, l, 1}, {g, 1, 1}, {yp, k, 1}, {u, l, 1}}, nullptr, 1, B);
+  rc = run_program(c, PG_LIN_U, 0, {{a2y, l, 0}, {g, 1, 0}, {yp, k, 0}, {u, l, 0}}, nullptr, 1, B);
   if (rc != RZK_OK) return rc;
   if (ok) {
     rc = run_norm(c, r, k, c->commit_bound, ok, B, 0, 0);
@@ -794,7 +793,7 @@ int rzk_linear_response_batch_dev(rzk_ctx* c, const int64_t* y, const int64_t* y
                                   const int64_t* rp, const int64_t* d, int64_t* z, int64_t* zp, size_t B) {
   if (!c || !y || !yp || !r || !rp || !d || !z || !zp) return RZK_E_ARG;
   const uint32_t k = c->k;
-  return run_program(c, PG_RESPONSE, 2, {{d, 1, 1}, {y, k, 1}, {r, k, 1}, {z, k, 1}, {yp, k, 1}, {rp, k, 1}, {zp, k, 1}},
+  return run_program(c, PG_RESPONSE, 2, {{d, 1, 0}, {y, k, 0}, {r, k, 0}, {z, k, 0}, {yp, k, 0}, {rp, k, 0}, {zp, k, 0}},
                      nullptr, 1, B);
 }
 
@@ -813,11 +812,11 @@ int rzk_linear_verify_batch_dev(rzk_ctx* c, const int64_t* z, const int64_t* zp,
   rc = run_norm(c, zp, k, c->verify_bound, accept, B, 1, 0);   // linear.rs:221-223
   if (rc != RZK_OK) return rc;
   rc = run_program(c, PG_LIN_V1, 0,
-                   {{z, k, 1}, {zp, k, 1}, {t, n, 1}, {tp, n, 1}, {cm, n + l, 1}, {cpm, n + l, 1}, {d, 1, 1}, {g, 1, 1},
-                    {w1, l, 1}, {w2, l, 1}},
+                   {{z, k, 0}, {zp, k, 0}, {t, n, 0}, {tp, n, 0}, {cm, n + l, 0}, {cpm, n + l, 0}, {d, 1, 0}, {g, 1, 0},
+                    {w1, l, 0}, {w2, l, 0}},
                    accept, 1, B);
   if (rc != RZK_OK) return rc;
-  return run_program(c, PG_LIN_V2, 0, {{w1, l, 1}, {w2, l, 1}, {g, 1, 1}, {d, 1, 1}, {zp, k, 1}, {u, l, 1}}, accept, 1, B);
+  return run_program(c, PG_LIN_V2, 0, {{w1, l, 0}, {w2, l, 0}, {g, 1, 0}, {d, 1, 0}, {zp, k, 0}, {u, l, 0}}, accept, 1, B);
 }
 
 // =================================================================================================
@@ -833,19 +832,19 @@ int rzk_sum_commit_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* gs, const in
   int64_t* xp = (int64_t*)c->ws.p;
   int64_t* w = xp + B * l * c->N;
   // sum.rs:107-115: xp = sum_i x_i (.) g_i
-  rc = run_program(c, PG_SUM_XP, V, {{xs, V * l, 1}, {gs, V, 1}, {xp, l, 1}}, nullptr, 1, B);
+  rc = run_program(c, PG_SUM_XP, V, {{xs, V * l, 0}, {gs, V, 0}, {xp, l, 0}}, nullptr, 1, B);
   if (rc != RZK_OK) return rc;
   // sum.rs:116 and 151: cp = commit(xp; rp), tp = a1.yp
-  rc = run_program(c, PG_OPEN_COMMIT, 0, {{xp, l, 1}, {rp, k, 1}, {yp, k, 1}, {cpm, n + l, 1}, {tp, n, 1}}, nullptr, 1, B);
+  rc = run_program(c, PG_OPEN_COMMIT, 0, {{xp, l, 0}, {rp, k, 0}, {yp, k, 0}, {cpm, n + l, 0}, {tp, n, 0}}, nullptr, 1, B);
   if (rc != RZK_OK) return rc;
   // sum.rs:117-120 and 145-148: c_i = commit(x_i; r_i), t_i = a1.y_i — the V summands are extra batch entries
-  rc = run_program(c, PG_OPEN_COMMIT, 0, {{xs, l, 1}, {rs, k, 1}, {ys, k, 1}, {cs, n + l, 1}, {ts, n, 1}}, nullptr, 1,
+  rc = run_program(c, PG_OPEN_COMMIT, 0, {{xs, l, 0}, {rs, k, 0}, {ys, k, 0}, {cs, n + l, 0}, {ts, n, 0}}, nullptr, 1,
                    B * V);
   if (rc != RZK_OK) return rc;
   // sum.rs:154-160: u = sum_i (a2.y_i)(.)g_i - a2.yp
-  rc = run_program(c, PG_MATVEC, RZK_KEY_A2 * 2, {{ys, k, 1}, {nullptr, l, 1}, {w, l, 1}}, nullptr, 1, B * V);
+  rc = run_program(c, PG_MATVEC, RZK_KEY_A2 * 2, {{ys, k, 0}, {nullptr, l, 0}, {w, l, 0}}, nullptr, 1, B * V);
   if (rc != RZK_OK) return rc;
-  rc = run_program(c, PG_SUM_U, V, {{w, V * l, 1}, {gs, V, 1}, {yp, k, 1}, {u, l, 1}}, nullptr, 1, B);
+  rc = run_program(c, PG_SUM_U, V, {{w, V * l, 0}, {gs, V, 0}, {yp, k, 0}, {u, l, 0}}, nullptr, 1, B);
   if (rc != RZK_OK) return rc;
   if (ok) {
     rc = run_norm(c, rp, k, c->commit_bound, ok, B, 0, 0);
@@ -860,10 +859,10 @@ int rzk_sum_response_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* ys, const 
   if (!c || V == 0 || !ys || !yp || !rs || !rp || !d || !zs || !zp) return RZK_E_ARG;
   const uint32_t k = c->k;
   // sum.rs:188-193: z_i = y_i + r_i (.) d — summands as batch entries, d shared by the V entries of a proof
-  int rc = run_program(c, PG_RESPONSE, 1, {{d, 1, V}, {ys, k, 1}, {rs, k, 1}, {zs, k, 1}}, nullptr, 1, B * V);
+  int rc = run_program(c, PG_RESPONSE, 1, {{d, 1, 1}, {ys, k, 0}, {rs, k, 0}, {zs, k, 0}}, nullptr, V, B * V);
   if (rc != RZK_OK) return rc;
   // sum.rs:195-197
-  return run_program(c, PG_RESPONSE, 1, {{d, 1, 1}, {yp, k, 1}, {rp, k, 1}, {zp, k, 1}}, nullptr, 1, B);
+  return run_program(c, PG_RESPONSE, 1, {{d, 1, 0}, {yp, k, 0}, {rp, k, 0}, {zp, k, 0}}, nullptr, 1, B);
 }
 
 int rzk_sum_verify_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* zs, const int64_t* zp, const int64_t* cs,
@@ -881,17 +880,17 @@ int rzk_sum_verify_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* zs, const in
   rc = run_norm(c, zp, k, c->verify_bound, accept, B, 1, 0);       // sum.rs:269-271
   if (rc != RZK_OK) return rc;
   // sum.rs:278-291: a1.z_i == t_i + c1_i (.) d for every summand (batch entries B*V, flag per proof)
-  rc = run_program(c, PG_A1_RELATION, 0, {{zs, k, 1}, {ts, n, 1}, {cs, n + l, 1}, {d, 1, V}}, accept, V, B * V);
+  rc = run_program(c, PG_A1_RELATION, 0, {{zs, k, 0}, {ts, n, 0}, {cs, n + l, 0}, {d, 1, 1}}, accept, V, B * V);
   if (rc != RZK_OK) return rc;
   // sum.rs:294-298
-  rc = run_program(c, PG_A1_RELATION, 0, {{zp, k, 1}, {tp, n, 1}, {cpm, n + l, 1}, {d, 1, 1}}, accept, 1, B);
+  rc = run_program(c, PG_A1_RELATION, 0, {{zp, k, 0}, {tp, n, 0}, {cpm, n + l, 0}, {d, 1, 0}}, accept, 1, B);
   if (rc != RZK_OK) return rc;
   // sum.rs:301-319
-  rc = run_program(c, PG_MATVEC, RZK_KEY_A2 * 2, {{zs, k, 1}, {nullptr, l, 1}, {w1, l, 1}}, nullptr, 1, B * V);
+  rc = run_program(c, PG_MATVEC, RZK_KEY_A2 * 2, {{zs, k, 0}, {nullptr, l, 0}, {w1, l, 0}}, nullptr, 1, B * V);
   if (rc != RZK_OK) return rc;
-  rc = run_program(c, PG_SUM_W2, V, {{cs, V * (n + l), 1}, {gs, V, 1}, {cpm, n + l, 1}, {w2, l, 1}}, nullptr, 1, B);
+  rc = run_program(c, PG_SUM_W2, V, {{cs, V * (n + l), 0}, {gs, V, 0}, {cpm, n + l, 0}, {w2, l, 0}}, nullptr, 1, B);
   if (rc != RZK_OK) return rc;
-  return run_program(c, PG_SUM_V3, V, {{w1, V * l, 1}, {gs, V, 1}, {zp, k, 1}, {w2, l, 1}, {d, 1, 1}, {u, l, 1}}, accept,
+  return run_program(c, PG_SUM_V3, V, {{w1, V * l, 0}, {gs, V, 0}, {zp, k, 0}, {w2, l, 0}, {d, 1, 0}, {u, l, 0}}, accept,
                      1, B);
 }
 

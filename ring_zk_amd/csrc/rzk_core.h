@@ -270,6 +270,9 @@ struct CrtConsts {
   uint32_t half3_d2;       // (P3+1)/2 = half3_lo + half3_d2 * (p0*p1)
   uint64_t half2;          // (p0*p1+1)/2
   uint64_t half3_lo;
+  // offset form: X' = X + H_np with H_np = (P_np - 1)/2 is non-negative, so no sign test is needed
+  uint32_t hmod[4][4];     // hmod[np][i] = H_np mod p_i
+  uint32_t hmodq[4];       // H_np mod q
 };
 
 // a*c*2^{-32} mod q as a signed value in (-q, q);  a, c < 2^32
@@ -319,6 +322,44 @@ RZK_HD int64_t crt_center(uint32_t r0, uint32_t r1, uint32_t r2, int np, const P
   }
   if (neg) s -= C.pmodq[np];
   return center_rounds<3>(s, C);
+}
+
+// ---- incremental (Garner) reconstruction in offset form -----------------------------------------------------
+// The kernels process the primes one after the other and fold each residue polynomial into a running
+// state as soon as its inverse transform is done, so only two 32-bit words per coefficient stay live:
+//   after prime 0:  stA = d0                     (first mixed-radix digit of X' = X + H_np)
+//   after prime 1:  stA = X' mod q (np == 2)  or (d0 + d1 p0) mod q,  stB = (d0 + d1 p0) mod p2 (np == 3)
+//   after prime 2:  stA = X' mod q
+// r is the lazy residue in [0,2p_i) left by the inverse transform.  Requires p0 < q.
+RZK_HD uint32_t crt_fold0(uint32_t r, int np, const PrimeConsts* pc, const CrtConsts& C) {
+  return csub(csub(r + C.hmod[np][0], pc[0].twop), pc[0].p);
+}
+RZK_HD uint32_t to_zq(int64_t s, const CrtConsts& C) {   // s in (-q, 2q) -> [0,q)
+  s = s < 0 ? s + (int64_t)C.q : s;
+  s = s >= (int64_t)C.q ? s - (int64_t)C.q : s;
+  return (uint32_t)s;
+}
+RZK_HD void crt_fold1(uint32_t r, int np, const PrimeConsts* pc, const CrtConsts& C, uint32_t& stA,
+                      uint32_t& stB) {
+  const uint32_t d0 = stA;
+  const uint32_t a1 = csub(csub(r + C.hmod[np][1], pc[1].twop), pc[1].p);
+  const uint32_t t1 = a1 + pc[1].p - csub(d0, pc[1].p);                      // (0, 2p1)
+  const uint32_t d1 = csub(mont_lazy(t1, C.inv01_r, pc[1].p, pc[1].npinv), pc[1].p);
+  stA = to_zq((int64_t)d0 + montq(d1, C.c1, C), C);
+  if (np == 3) {
+    const uint32_t m1 = mont_lazy(d1, C.p0_mod_p2_r, pc[2].p, pc[2].npinv);  // d1*p0 mod p2, [0,2p2)
+    stB = csub(csub(d0, pc[2].p) + m1, pc[2].twop);                          // (d0 + d1 p0) mod p2, [0,2p2)
+  }
+}
+RZK_HD void crt_fold2(uint32_t r, const PrimeConsts* pc, const CrtConsts& C, uint32_t& stA, uint32_t stB) {
+  const uint32_t a2 = csub(csub(r + C.hmod[3][2], pc[2].twop), pc[2].p);
+  const uint32_t t2 = a2 + pc[2].twop - stB;                                 // (0, 3p2)
+  const uint32_t d2 = csub(mont_lazy(t2, C.inv012_r, pc[2].p, pc[2].npinv), pc[2].p);
+  stA = to_zq((int64_t)stA + montq(d2, C.c2, C), C);
+}
+// X' mod q -> centred representative of X = X' - H_np
+RZK_HD int64_t crt_finish(uint32_t stA, int np, const CrtConsts& C) {
+  return center_rounds<1>((int64_t)stA - (int64_t)C.hmodq[np], C);
 }
 
 }  // namespace rzk

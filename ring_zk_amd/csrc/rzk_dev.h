@@ -7,10 +7,10 @@
 
 namespace rzk {
 
-// Constants every kernel receives by value (kernarg -> SGPRs).
+// Constants every kernel reads through a pointer to device memory (uniform -> scalar loads).
+// The twiddle tables are passed separately as one global pointer: table (2*prime + dir) of kTableLen
+// words, dir 0 = psi^{bitrev} * R (forward), dir 1 = psi^{-bitrev} * R (inverse).
 struct DevTables {
-  const uint32_t* tw_fwd[kMaxPrimes];   // psi^{bitrev}   * R, kTableLen entries each
-  const uint32_t* tw_inv[kMaxPrimes];   // psi^{-bitrev}  * R
   PrimeConsts pc[kMaxPrimes];
   CrtConsts crt;
   double cap[kMaxPrimes + 1];           // cap[np] = largest |exact result| np primes can represent
@@ -59,13 +59,14 @@ struct Program {
   AddTerm adds[kMaxAdds];
 };
 
-// Operand table of one launch: polynomial (op, off) of task-batch index b lives at
-// base[op] + ((b / div[op]) * stride[op] + off) * N.
+// Operand table of one launch.  The batch index b of a task may be a (proof, summand) pair:
+// bo = b / group is the proof.  Polynomial (op, off) lives at
+// base[op] + ((outer[op] ? bo : b) * stride[op] + off) * N ; verification flags are per proof (flags[bo]).
 struct Operands {
   int64_t* base[kMaxOperands];
   uint32_t stride[kMaxOperands];
-  uint32_t div[kMaxOperands];
-  uint32_t flag_div;   // flags[b / flag_div]
+  uint32_t outer[kMaxOperands];
+  uint32_t group;
   uint32_t pad;
 };
 
@@ -75,13 +76,13 @@ struct LaunchCfg {
   int num_cus;
 };
 
-int launch_row_program(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows,
+int launch_row_program(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows, bool has_vec,
                        const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf,
-                       const DevTables* d_T, uint8_t* d_flags, uint64_t batch);
+                       const DevTables* d_T, const uint32_t* d_tw, uint8_t* d_flags, uint64_t batch);
 int launch_key_transform(int logn, const LaunchCfg& cfg, const int64_t* d_key, uint32_t entries,
-                         uint32_t* d_key_ntt, const DevTables* d_T);
+                         uint32_t* d_key_ntt, const DevTables* d_T, const uint32_t* d_tw);
 int launch_ntt(int logn, bool inverse, const LaunchCfg& cfg, int prime, const uint32_t* d_in,
-               uint32_t* d_out, uint64_t count, const DevTables* d_T);
+               uint32_t* d_out, uint64_t count, const DevTables* d_T, const uint32_t* d_tw);
 int launch_addsub(const LaunchCfg& cfg, bool sub, const int64_t* a, const int64_t* b, int64_t* out,
                   uint64_t ncoef, const DevTables* d_T);
 // ok[b] = (all `rows` polys of proof b have sum c^2 < limit), limit = (bound+1)^2 given as hi:lo.

@@ -24,7 +24,7 @@ __device__ __forceinline__ void wave_sync() {
 }
 
 template <int LOGN>
-__device__ __forceinline__ void wave_fwd(uint32_t* x, int lane, uint32_t* lds, const uint32_t* tw,
+__device__ __forceinline__ void wave_fwd(uint32_t* x, int lane, uint32_t* lds, const uint32_t* __restrict__ tw,
                                          const PrimeConsts& pc) {
   fwd_phase1<LOGN>(x, tw, pc);
   lds_put_p1<LOGN>(x, lane, lds);
@@ -40,7 +40,7 @@ __device__ __forceinline__ void wave_fwd(uint32_t* x, int lane, uint32_t* lds, c
 }
 
 template <int LOGN>
-__device__ __forceinline__ void wave_inv(uint32_t* x, int lane, uint32_t* lds, const uint32_t* tw,
+__device__ __forceinline__ void wave_inv(uint32_t* x, int lane, uint32_t* lds, const uint32_t* __restrict__ tw,
                                          const PrimeConsts& pc) {
   inv_phase3<LOGN>(x, lane, tw, pc);
   lds_put_p3<LOGN>(x, lane, lds);
@@ -75,149 +75,169 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 }
 
 __device__ __forceinline__ const int64_t* operand_ptr(const Operands& ops, uint32_t op, uint32_t off,
-                                                       uint64_t b, int n_coef) {
-  const uint64_t poly = (b / ops.div[op]) * ops.stride[op] + off;
-  return ops.base[op] + poly * (uint64_t)n_coef;
+                                                       uint32_t b, uint32_t bo, int n_coef) {
+  const uint32_t idx = ops.outer[op] ? bo : b;
+  return ops.base[op] + ((uint64_t)idx * ops.stride[op] + off) * (uint64_t)n_coef;
 }
 
-// ||v||_1 and ||v||_inf of one coefficient polynomial (phase-1 / coalesced layout)
+// Load one coefficient polynomial (coalesced phase-1 layout), lift it into prime field `pc` and,
+// on the first prime pass, also return its 1-norm and max-norm (wave-uniform).
 template <int LOGN>
-__device__ __forceinline__ void poly_norms(const int64_t* __restrict__ p, int lane, double& l1,
-                                           double& linf) {
+__device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict__ src, int lane,
+                                          const PrimeConsts& pc, bool want_norms, double& l1, double& linf) {
   using G = Geo<LOGN>;
-  uint64_t s = 0;
-  uint32_t m = 0;
+  int32_t v[G::E];
 #pragma unroll
-  for (int e = 0; e < G::E; ++e) {
-    const int32_t v = (int32_t)p[G::j_p1(lane, e)];
-    const uint32_t a = (uint32_t)(v < 0 ? -v : v);
-    s += a;
-    m = a > m ? a : m;
+  for (int e = 0; e < G::E; ++e) v[e] = (int32_t)src[G::j_p1(lane, e)];
+  if (want_norms) {
+    uint64_t sum = 0;
+    uint32_t mx = 0;
+#pragma unroll
+    for (int e = 0; e < G::E; e += 2) {
+      const uint32_t a0 = (uint32_t)(v[e] < 0 ? -v[e] : v[e]);
+      const uint32_t a1 = (uint32_t)(v[e + 1] < 0 ? -v[e + 1] : v[e + 1]);
+      sum += (uint64_t)a0 + a1;
+      mx = a0 > mx ? a0 : mx;
+      mx = a1 > mx ? a1 : mx;
+    }
+    l1 = (double)wave_sum_u64(sum);
+    linf = (double)wave_max_u32(mx);
   }
-  l1 = (double)wave_sum_u64(s);
-  linf = (double)wave_max_u32(m);
+#pragma unroll
+  for (int e = 0; e < G::E; ++e) x[e] = lift(v[e], pc);
 }
 
 // =============================================================================================
 // Row-program kernel: the fused product / accumulate / reduce pipeline of every protocol phase.
+//
+// One wavefront evaluates one output row of one proof (rzk_dev.h).  Control flow is wave-uniform
+// and scalar (the wave index is read with readfirstlane).  Primes are processed one after the
+// other; the operands' norms are measured while they are loaded for the first prime, which fixes
+// how many primes (1..3) the exact result needs before any residue is folded into the running
+// Garner state (rzk_core.h, crt_fold*), so only two words per coefficient stay live across primes.
+// HAS_VEC = false is the lean instance for programs made of key products only.
 // =============================================================================================
-template <int LOGN>
-__global__ void __launch_bounds__(256)
+#ifndef RZK_ROW_MIN_WAVES
+#define RZK_ROW_MIN_WAVES 1   // minimum waves per SIMD the row kernel is compiled for (register budget)
+#endif
+template <int LOGN, bool HAS_VEC>
+__global__ void __launch_bounds__(256, RZK_ROW_MIN_WAVES)
 row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t* __restrict__ key_ntt,
-           const double* __restrict__ key_inf, const DevTables* __restrict__ Tp, uint8_t* __restrict__ flags,
-           const uint64_t batch) {
+           const double* __restrict__ key_inf, const DevTables* __restrict__ Tp,
+           const uint32_t* __restrict__ tw_all, uint8_t* __restrict__ flags, const uint32_t ntasks) {
   using G = Geo<LOGN>;
   constexpr int E = G::E;
   constexpr int N = G::N;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t* lds = smem + wave * G::LDS_WORDS;
   const DevTables& T = *Tp;
   const uint32_t nrows = prog->nrows;
-  const uint64_t ntasks = batch * nrows;
 
-  for (uint64_t task = (uint64_t)blockIdx.x * 4 + wave; task < ntasks; task += (uint64_t)gridDim.x * 4) {
-    const uint64_t b = task / nrows;
-    const uint32_t rowi = (uint32_t)(task - b * nrows);
+  for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
+    const uint32_t b = task / nrows;
+    const uint32_t rowi = task - b * nrows;
+    const uint32_t bo = ops.group > 1 ? b / ops.group : b;
     const Row row = prog->rows[rowi];
 
-    // ---- 1. how many primes does the exact integer result need?  |sum| <= sum_t ||a||_1 ||b||_inf
-    double bound = 0.0;
-#pragma unroll 1
-    for (uint32_t t = 0; t < row.nterms; ++t) {
-      const Term tm = prog->terms[row.term0 + t];
-      double l1b, infb;
-      poly_norms<LOGN>(operand_ptr(ops, tm.b_op, tm.b_off, b, N), lane, l1b, infb);
-      if (tm.kind == TERM_KEY) {
-        bound += key_inf[tm.a_off] * l1b;
-      } else {
-        double l1a, infa;
-        poly_norms<LOGN>(operand_ptr(ops, tm.a_op, tm.a_off, b, N), lane, l1a, infa);
-        const double u = l1a * infb, v = infa * l1b;
-        bound += u < v ? u : v;
-      }
-    }
-    bound *= 1.0 + 1e-9;   // the double products above are rounded; stay on the safe side
-    int np = bound <= T.cap[1] ? 1 : (bound <= T.cap[2] ? 2 : 3);
-    np = __builtin_amdgcn_readfirstlane(np);
-
-    // ---- 2. per prime: accumulate the products in the NTT domain, transform back once
-    uint32_t res0[E], res1[E], res2[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) res0[e] = res1[e] = res2[e] = 0;
-
+    int64_t s[E];
     if (row.nterms > 0) {
+      uint32_t stA[E], stB[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) stA[e] = stB[e] = 0;
+      int np = kMaxPrimes;
+      double bound = 0.0;
 #pragma unroll 1
-      for (int pi = np - 1; pi >= 0; --pi) {
+      for (int pi = 0; pi < np; ++pi) {
         const PrimeConsts pc = T.pc[pi];
-        const uint32_t* __restrict__ twf = T.tw_fwd[pi];
-        const uint32_t* __restrict__ twi = T.tw_inv[pi];
+        const uint32_t* __restrict__ twf = tw_all + (size_t)(2 * pi) * kTableLen;
+        const uint32_t* __restrict__ twi = twf + kTableLen;
+        const bool first = pi == 0;
         uint32_t acc[E];
 #pragma unroll
         for (int c = 0; c < E; ++c) acc[c] = 0;
 #pragma unroll 1
         for (uint32_t t = 0; t < row.nterms; ++t) {
           const Term tm = prog->terms[row.term0 + t];
-          uint32_t x[E], xb[E];
-          const int npass = tm.kind == TERM_VEC ? 2 : 1;
-#pragma unroll 1
-          for (int pass = 0; pass < npass; ++pass) {
-            const int64_t* __restrict__ src = pass == 0 ? operand_ptr(ops, tm.b_op, tm.b_off, b, N)
-                                                        : operand_ptr(ops, tm.a_op, tm.a_off, b, N);
+          uint32_t x[E];
+          double l1b = 0, infb = 0;
+          load_lift<LOGN>(x, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane, pc, first, l1b, infb);
+          wave_fwd<LOGN>(x, lane, lds, twf, pc);
+          if (HAS_VEC && tm.kind == TERM_VEC) {
+            // product of two per-proof polynomials: fold N^-1 and the Montgomery factor into one of them
+            uint32_t xb[E];
 #pragma unroll
-            for (int e = 0; e < E; ++e) x[e] = lift((int32_t)src[G::j_p1(lane, e)], pc);
+            for (int c = 0; c < E; ++c) xb[c] = csub(mont_lazy(x[c], pc.ninv_r2, pc.p, pc.npinv), pc.p);
+            double l1a = 0, infa = 0;
+            load_lift<LOGN>(x, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), lane, pc, first, l1a, infa);
             wave_fwd<LOGN>(x, lane, lds, twf, pc);
-            if (pass + 1 < npass) {
-              // second operand of a vec*vec term: fold N^-1 and the Montgomery factor in here
-#pragma unroll
-              for (int c = 0; c < E; ++c)
-                xb[c] = csub(mont_lazy(x[c], pc.ninv_r2, pc.p, pc.npinv), pc.p);
+            if (first) {
+              const double u = l1a * infb, v = infa * l1b;
+              bound += u < v ? u : v;
             }
-          }
-          if (tm.kind == TERM_KEY) {
-            const uint4* __restrict__ kp =
-                reinterpret_cast<const uint4*>(key_ntt + ((uint64_t)tm.a_off * kMaxPrimes + pi) * N);
+            if (tm.sign >= 0) {
 #pragma unroll
-            for (int g = 0; g < E / 4; ++g) {
-              const uint4 kv = kp[g * 64 + lane];
-              xb[4 * g + 0] = kv.x;
-              xb[4 * g + 1] = kv.y;
-              xb[4 * g + 2] = kv.z;
-              xb[4 * g + 3] = kv.w;
+              for (int c = 0; c < E; ++c) acc[c] = mac_add(acc[c], x[c], xb[c], pc);
+            } else {
+#pragma unroll
+              for (int c = 0; c < E; ++c) acc[c] = mac_sub(acc[c], x[c], xb[c], pc);
             }
-          }
-          if (tm.sign >= 0) {
-#pragma unroll
-            for (int c = 0; c < E; ++c) acc[c] = mac_add(acc[c], x[c], xb[c], pc);
           } else {
+            if (first) bound += key_inf[tm.a_off] * l1b;
+            const uint4* __restrict__ kp =
+                reinterpret_cast<const uint4*>(key_ntt + ((size_t)tm.a_off * kMaxPrimes + pi) * N);
+            if (tm.sign >= 0) {
 #pragma unroll
-            for (int c = 0; c < E; ++c) acc[c] = mac_sub(acc[c], x[c], xb[c], pc);
+              for (int g = 0; g < E / 4; ++g) {
+                const uint4 kv = kp[g * 64 + lane];
+                acc[4 * g + 0] = mac_add(acc[4 * g + 0], x[4 * g + 0], kv.x, pc);
+                acc[4 * g + 1] = mac_add(acc[4 * g + 1], x[4 * g + 1], kv.y, pc);
+                acc[4 * g + 2] = mac_add(acc[4 * g + 2], x[4 * g + 2], kv.z, pc);
+                acc[4 * g + 3] = mac_add(acc[4 * g + 3], x[4 * g + 3], kv.w, pc);
+              }
+            } else {
+#pragma unroll
+              for (int g = 0; g < E / 4; ++g) {
+                const uint4 kv = kp[g * 64 + lane];
+                acc[4 * g + 0] = mac_sub(acc[4 * g + 0], x[4 * g + 0], kv.x, pc);
+                acc[4 * g + 1] = mac_sub(acc[4 * g + 1], x[4 * g + 1], kv.y, pc);
+                acc[4 * g + 2] = mac_sub(acc[4 * g + 2], x[4 * g + 2], kv.z, pc);
+                acc[4 * g + 3] = mac_sub(acc[4 * g + 3], x[4 * g + 3], kv.w, pc);
+              }
+            }
           }
+        }
+        if (first) {
+          // |exact result| <= bound: pick the smallest prime count whose range covers it
+          bound *= 1.0 + 1e-9;   // the double products are rounded; stay on the safe side
+          np = bound <= T.cap[1] ? 1 : (bound <= T.cap[2] ? 2 : 3);
+          np = __builtin_amdgcn_readfirstlane(np);
         }
         wave_inv<LOGN>(acc, lane, lds, twi, pc);
+        if (pi == 0) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-          res2[e] = res1[e];
-          res1[e] = res0[e];
-          res0[e] = acc[e];
+          for (int e = 0; e < E; ++e) stA[e] = crt_fold0(acc[e], np, T.pc, T.crt);
+        } else if (pi == 1) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) crt_fold1(acc[e], np, T.pc, T.crt, stA[e], stB[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < E; ++e) crt_fold2(acc[e], T.pc, T.crt, stA[e], stB[e]);
         }
       }
-    }
-
-    // ---- 3. CRT -> centred mod q, plain additions, store / zero test
-    int64_t s[E];
-    if (row.nterms > 0) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) s[e] = crt_center(res0[e], res1[e], res2[e], np, T.pc, T.crt);
+      for (int e = 0; e < E; ++e) s[e] = crt_finish(stA[e], np, T.crt);
     } else {
 #pragma unroll
       for (int e = 0; e < E; ++e) s[e] = 0;
     }
+
+    // plain additions, then store / zero test
 #pragma unroll 1
     for (uint32_t a = 0; a < row.nadds; ++a) {
       const AddTerm ad = prog->adds[row.add0 + a];
-      const int64_t* __restrict__ src = operand_ptr(ops, ad.op, ad.off, b, N);
+      const int64_t* __restrict__ src = operand_ptr(ops, ad.op, ad.off, b, bo, N);
       if (ad.sign >= 0) {
 #pragma unroll
         for (int e = 0; e < E; ++e) s[e] = center_rounds<1>(s[e] + src[G::j_p1(lane, e)], T.crt);
@@ -227,14 +247,14 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
       }
     }
     if (row.mode == MODE_STORE) {
-      int64_t* __restrict__ dst = const_cast<int64_t*>(operand_ptr(ops, row.out_op, row.out_off, b, N));
+      int64_t* __restrict__ dst = const_cast<int64_t*>(operand_ptr(ops, row.out_op, row.out_off, b, bo, N));
 #pragma unroll
       for (int e = 0; e < E; ++e) dst[G::j_p1(lane, e)] = s[e];
     } else {
       int nz = 0;
 #pragma unroll
       for (int e = 0; e < E; ++e) nz |= (s[e] != 0);
-      if (__any(nz) && lane == 0) flags[b / ops.flag_div] = 0;
+      if (__any(nz) && lane == 0) flags[bo] = 0;
     }
   }
 }
@@ -245,14 +265,14 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
 template <int LOGN>
 __global__ void __launch_bounds__(256)
 key_transform_kernel(const int64_t* __restrict__ key, uint32_t entries, uint32_t* __restrict__ key_ntt,
-                     const DevTables* __restrict__ Tp) {
-  const DevTables& T = *Tp;
+                     const DevTables* __restrict__ Tp, const uint32_t* __restrict__ tw_all) {
   using G = Geo<LOGN>;
   constexpr int E = G::E;
   constexpr int N = G::N;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const DevTables& T = *Tp;
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t* lds = smem + wave * G::LDS_WORDS;
   const uint32_t ntasks = entries * kMaxPrimes;
   for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
@@ -263,7 +283,7 @@ key_transform_kernel(const int64_t* __restrict__ key, uint32_t entries, uint32_t
     uint32_t x[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) x[e] = lift((int32_t)src[G::j_p1(lane, e)], pc);
-    wave_fwd<LOGN>(x, lane, lds, T.tw_fwd[pi], pc);
+    wave_fwd<LOGN>(x, lane, lds, tw_all + (size_t)(2 * pi) * kTableLen, pc);
     uint4* __restrict__ dst = reinterpret_cast<uint4*>(key_ntt + ((uint64_t)entry * kMaxPrimes + pi) * N);
 #pragma unroll
     for (int g = 0; g < E / 4; ++g) {
@@ -283,17 +303,17 @@ key_transform_kernel(const int64_t* __restrict__ key, uint32_t entries, uint32_t
 template <int LOGN>
 __global__ void __launch_bounds__(256)
 ntt_fwd_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t count, int pi,
-               const DevTables* __restrict__ Tp) {
-  const DevTables& T = *Tp;
+               const DevTables* __restrict__ Tp, const uint32_t* __restrict__ tw_all) {
   using G = Geo<LOGN>;
   constexpr int E = G::E;
   constexpr int N = G::N;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const DevTables& T = *Tp;
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t* lds = smem + wave * G::LDS_WORDS;
   const PrimeConsts pc = T.pc[pi];
-  const uint32_t* __restrict__ tw = T.tw_fwd[pi];
+  const uint32_t* __restrict__ tw = tw_all + (size_t)(2 * pi) * kTableLen;
   for (uint64_t poly = (uint64_t)blockIdx.x * 4 + wave; poly < count; poly += (uint64_t)gridDim.x * 4) {
     const uint32_t* __restrict__ src = in + poly * N;
     uint32_t x[E];
@@ -316,17 +336,17 @@ ntt_fwd_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint
 template <int LOGN>
 __global__ void __launch_bounds__(256)
 ntt_inv_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint64_t count, int pi,
-               const DevTables* __restrict__ Tp) {
-  const DevTables& T = *Tp;
+               const DevTables* __restrict__ Tp, const uint32_t* __restrict__ tw_all) {
   using G = Geo<LOGN>;
   constexpr int E = G::E;
   constexpr int N = G::N;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const DevTables& T = *Tp;
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t* lds = smem + wave * G::LDS_WORDS;
   const PrimeConsts pc = T.pc[pi];
-  const uint32_t* __restrict__ tw = T.tw_inv[pi];
+  const uint32_t* __restrict__ tw = tw_all + (size_t)(2 * pi + 1) * kTableLen;
   for (uint64_t poly = (uint64_t)blockIdx.x * 4 + wave; poly < count; poly += (uint64_t)gridDim.x * 4) {
     const uint4* __restrict__ src = reinterpret_cast<const uint4*>(in + poly * N);
     uint32_t x[E];
@@ -369,7 +389,7 @@ addsub_kernel(const int64_t* a, const int64_t* b, int64_t* out, uint64_t n2, int
 
 // One wavefront per proof: all `rows` polynomials must satisfy sum c^2 < limit (= (bound+1)^2),
 // i.e. floor(sqrt(sum c^2)) <= bound (src/polynomial.rs:60-73, src/params.rs:105-107).
-// The sum is exact: c^2 split into 32-bit halves, accumulated in two 64-bit lanes-sums.
+// The sum is exact: c^2 split into 32-bit halves, accumulated in two 64-bit lane sums.
 template <int LOGN>
 __global__ void __launch_bounds__(256)
 norm_kernel(const int64_t* __restrict__ v, uint32_t rows, uint64_t limit_hi, uint64_t limit_lo,
@@ -378,7 +398,7 @@ norm_kernel(const int64_t* __restrict__ v, uint32_t rows, uint64_t limit_hi, uin
   constexpr int E = G::E;
   constexpr int N = G::N;
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (uint64_t b = (uint64_t)blockIdx.x * 4 + wave; b < B; b += (uint64_t)gridDim.x * 4) {
     int good = 1;
     for (uint32_t r = 0; r < rows; ++r) {
@@ -424,7 +444,7 @@ eq_kernel(const int64_t* __restrict__ a, const int64_t* __restrict__ b, uint32_t
   constexpr int E = G::E;
   constexpr int N = G::N;
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (uint64_t p = (uint64_t)blockIdx.x * 4 + wave; p < B; p += (uint64_t)gridDim.x * 4) {
     int ne = 0;
     for (uint32_t r = 0; r < rows; ++r) {
@@ -461,77 +481,84 @@ static inline unsigned grid_for(uint64_t tasks, int num_cus, int waves_per_block
     if (e_ != hipSuccess) return (int)e_;       \
   } while (0)
 
-template <int LOGN>
-static int launch_row_t(const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows, const Operands& ops,
+template <int LOGN, bool HAS_VEC>
+static int launch_row_t(const LaunchCfg& cfg, const Program* d_prog, const Operands& ops,
                         const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T,
-                        uint8_t* d_flags, uint64_t batch) {
+                        const uint32_t* d_tw, uint8_t* d_flags, uint32_t ntasks) {
   using G = Geo<LOGN>;
   const size_t lds = 4 * G::LDS_WORDS * sizeof(uint32_t);
-  const unsigned grid = grid_for(batch * nrows, cfg.num_cus);
-  hipLaunchKernelGGL(row_kernel<LOGN>, dim3(grid), dim3(256), lds, (hipStream_t)cfg.stream, d_prog, ops,
-                     d_key_ntt, d_key_inf, T, d_flags, batch);
+  const unsigned grid = grid_for(ntasks, cfg.num_cus);
+  hipLaunchKernelGGL((row_kernel<LOGN, HAS_VEC>), dim3(grid), dim3(256), lds, (hipStream_t)cfg.stream, d_prog,
+                     ops, d_key_ntt, d_key_inf, T, d_tw, d_flags, ntasks);
   RZK_LAUNCH_CHECK();
   return 0;
 }
 
-int launch_row_program(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows,
+int launch_row_program(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows, bool has_vec,
                        const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf,
-                       const DevTables* T, uint8_t* d_flags, uint64_t batch) {
+                       const DevTables* T, const uint32_t* d_tw, uint8_t* d_flags, uint64_t batch) {
   if (batch == 0 || nrows == 0) return 0;
+  if (batch * nrows >= (1ull << 32)) return -2;   // task index is 32-bit
+  const uint32_t ntasks = (uint32_t)(batch * nrows);
+#define RZK_ROW_CASE(L)                                                                                      \
+  case L:                                                                                                    \
+    return has_vec ? launch_row_t<L, true>(cfg, d_prog, ops, d_key_ntt, d_key_inf, T, d_tw, d_flags, ntasks) \
+                   : launch_row_t<L, false>(cfg, d_prog, ops, d_key_ntt, d_key_inf, T, d_tw, d_flags, ntasks);
   switch (logn) {
-    case 9: return launch_row_t<9>(cfg, d_prog, nrows, ops, d_key_ntt, d_key_inf, T, d_flags, batch);
-    case 10: return launch_row_t<10>(cfg, d_prog, nrows, ops, d_key_ntt, d_key_inf, T, d_flags, batch);
-    case 11: return launch_row_t<11>(cfg, d_prog, nrows, ops, d_key_ntt, d_key_inf, T, d_flags, batch);
+    RZK_ROW_CASE(9)
+    RZK_ROW_CASE(10)
+    RZK_ROW_CASE(11)
   }
+#undef RZK_ROW_CASE
   return -1;
 }
 
 template <int LOGN>
 static int launch_key_t(const LaunchCfg& cfg, const int64_t* d_key, uint32_t entries, uint32_t* d_key_ntt,
-                        const DevTables* T) {
+                        const DevTables* T, const uint32_t* d_tw) {
   using G = Geo<LOGN>;
   const size_t lds = 4 * G::LDS_WORDS * sizeof(uint32_t);
   const unsigned grid = grid_for((uint64_t)entries * kMaxPrimes, cfg.num_cus);
   hipLaunchKernelGGL(key_transform_kernel<LOGN>, dim3(grid), dim3(256), lds, (hipStream_t)cfg.stream,
-                     d_key, entries, d_key_ntt, T);
+                     d_key, entries, d_key_ntt, T, d_tw);
   RZK_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_key_transform(int logn, const LaunchCfg& cfg, const int64_t* d_key, uint32_t entries,
-                         uint32_t* d_key_ntt, const DevTables* T) {
+                         uint32_t* d_key_ntt, const DevTables* T, const uint32_t* d_tw) {
   if (entries == 0) return 0;
   switch (logn) {
-    case 9: return launch_key_t<9>(cfg, d_key, entries, d_key_ntt, T);
-    case 10: return launch_key_t<10>(cfg, d_key, entries, d_key_ntt, T);
-    case 11: return launch_key_t<11>(cfg, d_key, entries, d_key_ntt, T);
+    case 9: return launch_key_t<9>(cfg, d_key, entries, d_key_ntt, T, d_tw);
+    case 10: return launch_key_t<10>(cfg, d_key, entries, d_key_ntt, T, d_tw);
+    case 11: return launch_key_t<11>(cfg, d_key, entries, d_key_ntt, T, d_tw);
   }
   return -1;
 }
 
 template <int LOGN>
 static int launch_ntt_t(bool inverse, const LaunchCfg& cfg, int prime, const uint32_t* d_in, uint32_t* d_out,
-                        uint64_t count, const DevTables* T) {
+                        uint64_t count, const DevTables* T, const uint32_t* d_tw) {
   using G = Geo<LOGN>;
   const size_t lds = 4 * G::LDS_WORDS * sizeof(uint32_t);
   const unsigned grid = grid_for(count, cfg.num_cus);
   if (inverse)
     hipLaunchKernelGGL(ntt_inv_kernel<LOGN>, dim3(grid), dim3(256), lds, (hipStream_t)cfg.stream, d_in,
-                       d_out, count, prime, T);
+                       d_out, count, prime, T, d_tw);
   else
     hipLaunchKernelGGL(ntt_fwd_kernel<LOGN>, dim3(grid), dim3(256), lds, (hipStream_t)cfg.stream, d_in,
-                       d_out, count, prime, T);
+                       d_out, count, prime, T, d_tw);
   RZK_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_ntt(int logn, bool inverse, const LaunchCfg& cfg, int prime, const uint32_t* d_in,
-               uint32_t* d_out, uint64_t count, const DevTables* T) {
+               uint32_t* d_out, uint64_t count, const DevTables* T, const uint32_t* d_tw) {
   if (count == 0) return 0;
   switch (logn) {
-    case 9: return launch_ntt_t<9>(inverse, cfg, prime, d_in, d_out, count, T);
-    case 10: return launch_ntt_t<10>(inverse, cfg, prime, d_in, d_out, count, T);
-    case 11: return launch_ntt_t<11>(inverse, cfg, prime, d_in, d_out, count, T);
+    case 9: return launch_ntt_t<9>(inverse, cfg, prime, d_in, d_out, count, T, d_tw);
+    case 10: return launch_ntt_t<10>(inverse, cfg, prime, d_in, d_out, count, T, d_tw);
+    case 11: return launch_ntt_t<11>(inverse, cfg, prime, d_in, d_out, count, T, d_tw);
   }
   return -1;
 }

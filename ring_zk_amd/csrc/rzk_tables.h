@@ -87,6 +87,7 @@ inline void make_twiddles(int pi, std::vector<uint32_t>& fwd, std::vector<uint32
 inline bool make_crt_consts(uint64_t q, CrtConsts& C) {
   if ((q & 1) == 0 || q < 3 || q >= (1ull << 32)) return false;
   if ((q - 1) / 2 >= 2ull * kPrimes[kMaxPrimes - 1]) return false;
+  if (q <= kPrimes[0]) return false;   // the reconstruction keeps digits below p0 as residues mod q
   const uint64_t p0 = kPrimes[0], p1 = kPrimes[1], p2 = kPrimes[2];
   C.q = (uint32_t)q;
   C.qinv = inv_u32((uint32_t)q);
@@ -106,6 +107,13 @@ inline bool make_crt_consts(uint64_t q, CrtConsts& C) {
   const u128 h3 = (P3 + 1) / 2;
   C.half3_d2 = (uint32_t)(h3 / (p0 * p1));
   C.half3_lo = (uint64_t)(h3 % (p0 * p1));
+  for (int np = 0; np <= kMaxPrimes; ++np) {
+    u128 P = 1;
+    for (int i = 0; i < np; ++i) P *= kPrimes[i];
+    const u128 H = (P - 1) / 2;
+    for (int i = 0; i < 4; ++i) C.hmod[np][i] = i < kMaxPrimes ? (uint32_t)(H % kPrimes[i]) : 0;
+    C.hmodq[np] = (uint32_t)(H % q);
+  }
   return true;
 }
 

@@ -103,8 +103,16 @@ int polymul(int np, uint64_t q, const int64_t* a, const int64_t* b, int64_t* out
     std::memcpy(res[pi], wa.x, sizeof(wa.x));
   }
   for (int l = 0; l < 64; ++l)
-    for (int e = 0; e < G::E; ++e)
-      out[G::j_p1(l, e)] = crt_center(res[0][l][e], res[1][l][e], res[2][l][e], np, pc, C);
+    for (int e = 0; e < G::E; ++e) {
+      // both reconstruction forms must agree: sign-test form and the incremental offset form the kernels use
+      const int64_t v1 = crt_center(res[0][l][e], res[1][l][e], res[2][l][e], np, pc, C);
+      uint32_t stA = crt_fold0(res[0][l][e], np, pc, C), stB = 0;
+      if (np >= 2) crt_fold1(res[1][l][e], np, pc, C, stA, stB);
+      if (np >= 3) crt_fold2(res[2][l][e], pc, C, stA, stB);
+      const int64_t v2 = crt_finish(stA, np, C);
+      if (v1 != v2) return -2;
+      out[G::j_p1(l, e)] = v2;
+    }
   return 0;
 }
 

@@ -100,7 +100,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    from ring_zk_amd import Context, synth
+    from ring_zk_amd import Context, shard, synth
 
     N, n, k, l = args.N, 1, 3, 1
     B = args.batch
@@ -128,9 +128,7 @@ def main():
         return ok, acc
 
     def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+        shard.barrier(dist, dev)
 
     for _ in range(args.warmup):
         ok, acc = step()
@@ -145,12 +143,7 @@ def main():
     ok_cnt = int(ok.sum().item())
     assert accepted == B and ok_cnt == B, f"rank {rank}: {accepted}/{B} accepted, {ok_cnt}/{B} commit-ok"
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    tot_acc = torch.tensor([accepted], dtype=torch.int64, device=dev)
-    if dist is not None:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot_acc, op=dist.ReduceOp.SUM)
-    elapsed = float(el.item())
+    elapsed, tot_acc = shard.reduce_result(dist, elapsed, accepted, dev)
     proofs = B * world * args.steps
     value = proofs / elapsed
 
@@ -191,7 +184,8 @@ def main():
             "algorithmic_bytes_per_launch": per_launch,
         }
         # stand-alone batched forward NTT (one residue polynomial = 2*N*4 algorithmic bytes)
-        cnt = 4 * 4096
+        # 65536 x 4 KiB in + the same out = 512 MiB per launch: beyond the 256 MiB Infinity Cache
+        cnt = 16 * 4096
         xin = torch.randint(0, ctx.ntt_prime(0), (cnt, N), dtype=torch.int32, device=dev)
         xout = torch.empty_like(xin)
         ntt_us = ctx.bench_ntt_forward(0, xin, xout, 20)
@@ -221,7 +215,7 @@ def main():
                 "workload": f"OpenProof cycle, N={N}, (n,k,l)=({n},{k},{l}), kappa=36, batch={B} proofs per GPU",
                 "challenge": "pre-sampled (host RNG is outside the path)",
                 "parallelism": f"batch split over {world} GPU(s), no data-path collective",
-                "accepted": int(tot_acc.item()),
+                "accepted": tot_acc,
             },
             "roofline": roofline,
             "ntt_roofline": ntt,

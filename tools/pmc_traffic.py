@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; csv output) of bench.py into HBM bytes per
+row-kernel launch, as /opt/skills/guides/MI355X_MICROARCH.md §HBM prescribes:
+
+  * FETCH_SIZE / WRITE_SIZE are in KiB; collected in separate passes (TCC slots);
+  * on gfx950 FETCH_SIZE reports half of the bytes of a coalesced streaming read, so it is calibrated
+    on kernels of the SAME run whose byte count is known exactly and whose access pattern is the same:
+    norm_kernel (reads B*k polynomials of 8*N bytes with the row kernel's 8-byte-per-lane loads) and
+    ntt_fwd_kernel (reads count*N*4 bytes);  WRITE_SIZE needs no correction (checked on ntt_fwd_kernel).
+
+usage: tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> [out.json]
+"""
+import collections
+import csv
+import json
+import sys
+
+N, B, K, NTT_POLYS = 1024, 4096, 3, 65536
+
+
+def load(path, counter):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter and "rzk::" in r["Kernel_Name"]:
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            agg[(name, int(r["Grid_Size"]))].append(float(r["Counter_Value"]) * 1024.0)
+    return {k: sum(v) / len(v) for k, v in agg.items()}, {k: len(v) for k, v in agg.items()}
+
+
+def main():
+    fetch, nf = load(sys.argv[1], "FETCH_SIZE")
+    write, _ = load(sys.argv[2], "WRITE_SIZE")
+    norm_key = [k for k in fetch if "norm_kernel" in k[0]][0]
+    ntt_key = [k for k in fetch if "ntt_fwd_kernel" in k[0]][0]
+    cal_norm = (B * K * N * 8) / fetch[norm_key]
+    cal_ntt = (NTT_POLYS * N * 4) / fetch[ntt_key]
+    wr_check = write[ntt_key] / (NTT_POLYS * N * 4)
+    rows = {}
+    for k in fetch:
+        if "row_kernel" in k[0]:
+            rows[f"{k[0]} grid={k[1]}"] = {
+                "launches": nf[k],
+                "fetch_bytes_raw": fetch[k],
+                "fetch_bytes_corrected": fetch[k] * cal_norm,
+                "write_bytes": write.get(k, 0.0),
+            }
+    total = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in rows.values())
+    out = {
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py --steps 3",
+        "fetch_calibration_norm_kernel": cal_norm,
+        "fetch_calibration_ntt_fwd_kernel": cal_ntt,
+        "write_size_over_known_bytes_ntt_fwd": wr_check,
+        "row_kernel_launches_per_cycle": rows,
+        "hbm_bytes_per_cycle": total,
+        "hbm_bytes_per_launch": total / max(len(rows), 1),
+        "algorithmic_bytes_per_launch": 26 * 8 * N * B / 3.0,
+    }
+    out["traffic_over_algorithmic"] = out["hbm_bytes_per_launch"] / out["algorithmic_bytes_per_launch"]
+    text = json.dumps(out, indent=1)
+    print(text)
+    if len(sys.argv) > 3:
+        open(sys.argv[3], "w").write(text + "\n")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,486 @@
+// ring_zk.hpp — C++ host mirror of the reference's public API over the C ABI (include/rzk.h).
+//
+// The reference is a Rust crate (no toolchain for it in this image), so this header plays the role of
+// the Rust shim of INTEGRATION.md: the same types and method names as src/lib.rs:5-24 —
+// Params, CommitmentKey, Commitment, Opening, {Open,Linear,Sum}Proof{Prover,Verifier} — with every ring
+// operation delegated to librzk_hip.so.  Sampling (random_polynomial_within, the rounded Gaussian,
+// the challenge set; src/polynomial.rs:14-44, src/challenge_space.rs:12-33) stays on the host, as in
+// the reference.  Shape mismatches throw std::runtime_error where the reference panics.
+//
+// Single-proof calls (batch = 1) go through the host-pointer entry points; that is the drop-in
+// behaviour, not the fast path — batches use the *_batch entry points directly.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "../../include/rzk.h"
+
+namespace ring_zk {
+
+using Poly = std::vector<int64_t>;     // N dense centred coefficients (Polynomial<ZqI64<Q>, N>)
+using PolyVec = std::vector<Poly>;     // Vec<Polynomial> / an (m x 1) Mat
+using Rng = std::mt19937_64;
+
+constexpr int64_t kDefaultQ = 3515337053LL;   // ZqI64<3515337053>, src/params.rs:121
+
+// src/params.rs:18-36 (+ the ring modulus, which the reference carries as the const generic of ZqI64)
+struct Params {
+  int64_t modulus = kDefaultQ;
+  int64_t q = kDefaultQ / 2;   // sampling bound of key / message coefficients (params.rs:126)
+  uint64_t b = 1;
+  size_t n = 1, k = 3, l = 1, kappa = 36;
+
+  static uint64_t isqrt(uint64_t x) {
+    uint64_t r = (uint64_t)std::sqrt((long double)x);
+    while (r * r > x) --r;
+    while ((r + 1) * (r + 1) <= x) ++r;
+    return r;
+  }
+  // params.rs:94-98
+  uint64_t standard_deviation(size_t deg_n) const { return b * (11 * kappa) * isqrt(k * deg_n); }
+};
+
+inline void flatten(const PolyVec& v, size_t N, std::vector<int64_t>& out) {
+  for (const Poly& p : v) {
+    if (p.size() > N) throw std::runtime_error("polynomial longer than the ring degree");
+    const size_t start = out.size();
+    out.insert(out.end(), p.begin(), p.end());
+    out.resize(start + N, 0);   // trimmed representation (mat.rs:430-434) -> dense slab
+  }
+}
+inline Poly dense(const Poly& p, size_t N) {   // zero-pad a trimmed polynomial to N coefficients
+  if (p.size() > N) throw std::runtime_error("polynomial longer than the ring degree");
+  Poly d(p);
+  d.resize(N, 0);
+  return d;
+}
+inline PolyVec unflatten(const std::vector<int64_t>& flat, size_t N) {
+  PolyVec out;
+  for (size_t i = 0; i + N <= flat.size(); i += N) out.emplace_back(flat.begin() + i, flat.begin() + i + N);
+  return out;
+}
+
+// one rzk_ctx per (Params, N); shared by key, provers and verifiers
+template <size_t N>
+class Backend {
+ public:
+  explicit Backend(const Params& p, int device = 0) : params(p) {
+    if (rzk_ctx_create(&ctx_, p.modulus, (uint32_t)N, (uint32_t)p.n, (uint32_t)p.k, (uint32_t)p.l,
+                       (uint32_t)p.kappa, p.b, device) != RZK_OK)
+      throw std::runtime_error(std::string("rzk_ctx_create: ") + rzk_last_error(nullptr));
+  }
+  ~Backend() { rzk_ctx_destroy(ctx_); }
+  Backend(const Backend&) = delete;
+  Backend& operator=(const Backend&) = delete;
+  rzk_ctx* ctx() const { return ctx_; }
+  void check(int st) const {
+    if (st != RZK_OK) throw std::runtime_error(std::string("rzk: ") + rzk_last_error(ctx_));   // reference: panic!
+  }
+  Params params;
+
+ private:
+  rzk_ctx* ctx_ = nullptr;
+};
+
+// ---- samplers (host side, as in the reference) -------------------------------------------------------------
+template <size_t N>
+Poly random_polynomial_within(Rng& rng, int64_t bound) {   // polynomial.rs:14-25
+  std::uniform_int_distribution<int64_t> d(-bound, bound);
+  Poly p(N);
+  for (auto& c : p) c = d(rng);
+  return p;
+}
+template <size_t N>
+Poly random_polynomial_in_normal_distribution(Rng& rng, double mean, double std_dev) {   // polynomial.rs:28-44
+  std::normal_distribution<double> d(mean, std_dev);
+  Poly p(N);
+  for (auto& c : p) c = (int64_t)d(rng);
+  return p;
+}
+template <size_t N>
+Poly random_polynomial_from_challenge_set(Rng& rng, size_t kappa) {   // challenge_space.rs:12-33
+  Poly p(N, 0);
+  for (size_t i = 0; i < std::min(kappa, N); ++i) p[i] = (rng() & 1) ? 1 : -1;
+  std::shuffle(p.begin(), p.end(), rng);
+  return p;
+}
+
+// ---- commitment scheme (src/commit.rs) ----------------------------------------------------------------------
+template <size_t N>
+struct Opening {
+  PolyVec x, r;   // f is always None when produced by the crate (commit.rs:127)
+};
+
+template <size_t N>
+class CommitmentKey {
+ public:
+  // CommitmentKey::new (commit.rs:33-60); loads [a1;a2] into the backend (resident, NTT domain)
+  CommitmentKey(Rng& rng, std::shared_ptr<Backend<N>> be) : be_(std::move(be)) {
+    const Params& P = be_->params;
+    const Poly zero(N, 0);
+    Poly one(N, 0);
+    one[0] = 1;
+    for (size_t i = 0; i < P.n; ++i) {          // a1 = [I_n | a1']
+      for (size_t j = 0; j < P.n; ++j) a.push_back(i == j ? one : zero);
+      for (size_t j = P.n; j < P.k; ++j) a.push_back(random_polynomial_within<N>(rng, P.q));
+    }
+    for (size_t i = 0; i < P.l; ++i) {          // a2 = [0 | I_l | a2']
+      for (size_t j = 0; j < P.n; ++j) a.push_back(zero);
+      for (size_t j = 0; j < P.l; ++j) a.push_back(i == j ? one : zero);
+      for (size_t j = P.n + P.l; j < P.k; ++j) a.push_back(random_polynomial_within<N>(rng, P.q));
+    }
+    std::vector<int64_t> flat;
+    flatten(a, N, flat);
+    be_->check(rzk_key_load(be_->ctx(), flat.data()));
+  }
+
+  // commit (commit.rs:88-128): resample r until check_commit_constraint holds, c = [a1;a2].r + [0;x]
+  std::pair<Opening<N>, PolyVec> commit(Rng& rng, const PolyVec& x) const {
+    const Params& P = be_->params;
+    if (x.size() != P.l) throw std::runtime_error("commit: x.len() != l (commit.rs:95)");
+    std::vector<int64_t> xf, zf((P.n + P.l) * N, 0), cf((P.n + P.l) * N);
+    flatten(x, N, xf);
+    std::copy(xf.begin(), xf.end(), zf.begin() + P.n * N);   // z = [0_n ; x] (commit.rs:116-121)
+    PolyVec r;
+    std::vector<int64_t> rf;
+    for (;;) {
+      r.clear();
+      for (size_t i = 0; i < P.k; ++i) r.push_back(random_polynomial_within<N>(rng, (int64_t)P.b));
+      rf.clear();
+      flatten(r, N, rf);
+      uint8_t ok = 0;
+      be_->check(rzk_norm2_le_batch(be_->ctx(), rf.data(), (uint32_t)P.k, rzk_commit_bound(be_->ctx()), &ok, 1));
+      if (ok) break;
+    }
+    be_->check(rzk_matvec_batch(be_->ctx(), RZK_KEY_A, rf.data(), zf.data(), cf.data(), 1));   // a.dot(&r).add(&z)
+    return {Opening<N>{x, r}, unflatten(cf, N)};
+  }
+  const std::shared_ptr<Backend<N>>& backend() const { return be_; }
+  PolyVec a;   // (n+l)*k polynomials, row-major
+
+ private:
+  std::shared_ptr<Backend<N>> be_;
+};
+
+// Commitment::verify with f = None (commit.rs:173-210)
+template <size_t N>
+bool commitment_verify(const PolyVec& c, const Opening<N>& o, const CommitmentKey<N>& ck) {
+  const auto& be = ck.backend();
+  const Params& P = be->params;
+  std::vector<int64_t> rf, xf, zf((P.n + P.l) * N, 0), cf, got((P.n + P.l) * N);
+  flatten(o.r, N, rf);
+  flatten(o.x, N, xf);
+  flatten(c, N, cf);
+  uint8_t ok = 0, eq = 0;
+  be->check(rzk_norm2_le_batch(be->ctx(), rf.data(), (uint32_t)P.k, rzk_commit_bound(be->ctx()), &ok, 1));
+  if (!ok) return false;
+  std::copy(xf.begin(), xf.end(), zf.begin() + P.n * N);
+  be->check(rzk_matvec_batch(be->ctx(), RZK_KEY_A, rf.data(), zf.data(), got.data(), 1));
+  be->check(rzk_eq_batch(be->ctx(), got.data(), cf.data(), (uint32_t)(P.n + P.l), &eq, 1));
+  return eq != 0;
+}
+
+// ---- OpenProof (src/prove/open.rs) ----------------------------------------------------------------------------
+template <size_t N>
+struct OpenProofResponseContext { Opening<N> opening; PolyVec y; };
+template <size_t N>
+struct OpenProofCommitment { PolyVec c, t; };
+template <size_t N>
+struct OpenProofVerificationContext { PolyVec c, t; Poly d; };
+struct OpenProofChallenge { Poly d; };
+struct OpenProofResponse { PolyVec z; };
+
+template <size_t N>
+class OpenProofProver {
+ public:
+  explicit OpenProofProver(const CommitmentKey<N>& ck) : ck_(ck) {}
+  // open.rs:80-103
+  std::pair<OpenProofResponseContext<N>, OpenProofCommitment<N>> commit(Rng& rng, const PolyVec& x) const {
+    const auto& be = ck_.backend();
+    const Params& P = be->params;
+    auto oc = ck_.commit(rng, x);
+    PolyVec y;
+    for (size_t i = 0; i < P.k; ++i)
+      y.push_back(random_polynomial_in_normal_distribution<N>(rng, 0.0, (double)P.standard_deviation(N)));
+    std::vector<int64_t> yf, tf(P.n * N);
+    flatten(y, N, yf);
+    be->check(rzk_matvec_batch(be->ctx(), RZK_KEY_A1, yf.data(), nullptr, tf.data(), 1));   // t = a1.dot(&y)
+    return {OpenProofResponseContext<N>{oc.first, y}, OpenProofCommitment<N>{oc.second, unflatten(tf, N)}};
+  }
+  // open.rs:107-117: z = y + r (.) d
+  OpenProofResponse create_response(const OpenProofResponseContext<N>& ctx, const OpenProofChallenge& ch) const {
+    const auto& be = ck_.backend();
+    std::vector<int64_t> yf, rf, zf(be->params.k * N);
+    flatten(ctx.y, N, yf);
+    flatten(ctx.opening.r, N, rf);
+    be->check(rzk_open_response_batch(be->ctx(), yf.data(), rf.data(), ch.d.data(), zf.data(), 1));
+    return {unflatten(zf, N)};
+  }
+
+ private:
+  const CommitmentKey<N>& ck_;
+};
+
+template <size_t N>
+class OpenProofVerifier {
+ public:
+  explicit OpenProofVerifier(const CommitmentKey<N>& ck) : ck_(ck) {}
+  // open.rs:143-158
+  std::pair<OpenProofVerificationContext<N>, OpenProofChallenge> generate_challenge(
+      Rng& rng, const OpenProofCommitment<N>& cm) const {
+    Poly d = random_polynomial_from_challenge_set<N>(rng, ck_.backend()->params.kappa);
+    return {OpenProofVerificationContext<N>{cm.c, cm.t, d}, OpenProofChallenge{d}};
+  }
+  // open.rs:162-174
+  bool verify(const OpenProofResponse& resp, const OpenProofVerificationContext<N>& v) const {
+    const auto& be = ck_.backend();
+    std::vector<int64_t> zf, tf, cf;
+    flatten(resp.z, N, zf);
+    flatten(v.t, N, tf);
+    flatten(v.c, N, cf);
+    if (zf.size() != be->params.k * N) throw std::runtime_error("verify: response has the wrong shape");
+    uint8_t acc = 0;
+    be->check(rzk_open_verify_batch(be->ctx(), zf.data(), tf.data(), cf.data(), v.d.data(), &acc, 1));
+    return acc != 0;
+  }
+
+ private:
+  const CommitmentKey<N>& ck_;
+};
+
+// ---- LinearProof (src/prove/linear.rs) ------------------------------------------------------------------------------
+template <size_t N>
+struct LinearProofResponseContext { Opening<N> opening, opening_p; PolyVec y, yp; };
+template <size_t N>
+struct LinearProofCommitment { PolyVec c, cp; Poly g; PolyVec t, tp, u; };
+template <size_t N>
+struct LinearProofVerificationContext { LinearProofCommitment<N> cm; Poly d; };
+struct LinearProofChallenge { Poly d; };
+struct LinearProofResponse { PolyVec z, zp; };
+
+template <size_t N>
+class LinearProofProver {
+ public:
+  explicit LinearProofProver(const CommitmentKey<N>& ck) : ck_(ck) {}
+  // linear.rs:82-140
+  std::pair<LinearProofResponseContext<N>, LinearProofCommitment<N>> commit(Rng& rng, const Poly& g_in,
+                                                                          const PolyVec& x) const {
+    const Poly g = dense(g_in, N);
+    const auto& be = ck_.backend();
+    const Params& P = be->params;
+    if (x.size() != P.l) throw std::runtime_error("commit: x.len() != l");
+    std::vector<int64_t> xf, gxf(P.l * N);
+    flatten(x, N, xf);
+    be->check(rzk_cmul_batch(be->ctx(), xf.data(), (uint32_t)P.l, g.data(), gxf.data(), 1));   // gx = x_i * g
+    auto ocp = ck_.commit(rng, unflatten(gxf, N));
+    auto oc = ck_.commit(rng, x);
+    PolyVec y, yp;
+    const double sd = (double)P.standard_deviation(N);
+    for (size_t i = 0; i < P.k; ++i) y.push_back(random_polynomial_in_normal_distribution<N>(rng, 0.0, sd));
+    for (size_t i = 0; i < P.k; ++i) yp.push_back(random_polynomial_in_normal_distribution<N>(rng, 0.0, sd));
+    std::vector<int64_t> yf, ypf, tf(P.n * N), tpf(P.n * N), a2y(P.l * N), a2yp(P.l * N), uf(P.l * N);
+    flatten(y, N, yf);
+    flatten(yp, N, ypf);
+    be->check(rzk_matvec_batch(be->ctx(), RZK_KEY_A1, yf.data(), nullptr, tf.data(), 1));
+    be->check(rzk_matvec_batch(be->ctx(), RZK_KEY_A1, ypf.data(), nullptr, tpf.data(), 1));
+    // u = (a2.y) (.) g - a2.yp  (linear.rs:124-129), composed from the Mat primitives
+    be->check(rzk_matvec_batch(be->ctx(), RZK_KEY_A2, yf.data(), nullptr, a2y.data(), 1));
+    be->check(rzk_cmul_batch(be->ctx(), a2y.data(), (uint32_t)P.l, g.data(), uf.data(), 1));
+    be->check(rzk_matvec_batch(be->ctx(), RZK_KEY_A2, ypf.data(), nullptr, a2yp.data(), 1));
+    be->check(rzk_sub_batch(be->ctx(), uf.data(), a2yp.data(), uf.data(), P.l));
+    return {LinearProofResponseContext<N>{oc.first, ocp.first, y, yp},
+            LinearProofCommitment<N>{oc.second, ocp.second, g, unflatten(tf, N), unflatten(tpf, N), unflatten(uf, N)}};
+  }
+  // linear.rs:144-158
+  LinearProofResponse create_response(const LinearProofResponseContext<N>& ctx, const LinearProofChallenge& ch) const {
+    const auto& be = ck_.backend();
+    const size_t kN = be->params.k * N;
+    std::vector<int64_t> yf, ypf, rf, rpf, zf(kN), zpf(kN);
+    flatten(ctx.y, N, yf);
+    flatten(ctx.yp, N, ypf);
+    flatten(ctx.opening.r, N, rf);
+    flatten(ctx.opening_p.r, N, rpf);
+    be->check(rzk_linear_response_batch(be->ctx(), yf.data(), ypf.data(), rf.data(), rpf.data(), ch.d.data(),
+                                        zf.data(), zpf.data(), 1));
+    return {unflatten(zf, N), unflatten(zpf, N)};
+  }
+
+ private:
+  const CommitmentKey<N>& ck_;
+};
+
+template <size_t N>
+class LinearProofVerifier {
+ public:
+  explicit LinearProofVerifier(const CommitmentKey<N>& ck) : ck_(ck) {}
+  std::pair<LinearProofVerificationContext<N>, LinearProofChallenge> generate_challenge(
+      Rng& rng, const LinearProofCommitment<N>& cm) const {   // linear.rs:184-209
+    Poly d = random_polynomial_from_challenge_set<N>(rng, ck_.backend()->params.kappa);
+    return {LinearProofVerificationContext<N>{cm, d}, LinearProofChallenge{d}};
+  }
+  bool verify(const LinearProofResponse& r, const LinearProofVerificationContext<N>& v) const {   // linear.rs:213-250
+    const auto& be = ck_.backend();
+    std::vector<int64_t> zf, zpf, cf, cpf, tf, tpf, uf;
+    flatten(r.z, N, zf);
+    flatten(r.zp, N, zpf);
+    flatten(v.cm.c, N, cf);
+    flatten(v.cm.cp, N, cpf);
+    flatten(v.cm.t, N, tf);
+    flatten(v.cm.tp, N, tpf);
+    flatten(v.cm.u, N, uf);
+    uint8_t acc = 0;
+    be->check(rzk_linear_verify_batch(be->ctx(), zf.data(), zpf.data(), cf.data(), cpf.data(), v.cm.g.data(), tf.data(),
+                                      tpf.data(), uf.data(), v.d.data(), &acc, 1));
+    return acc != 0;
+  }
+
+ private:
+  const CommitmentKey<N>& ck_;
+};
+
+// ---- SumProof (src/prove/sum.rs) -------------------------------------------------------------------------------------
+template <size_t N>
+struct SumProofResponseContext { std::vector<Opening<N>> openings; Opening<N> opening_p; PolyVec yp; std::vector<PolyVec> ys; };
+template <size_t N>
+struct SumProofCommitment { PolyVec cp; std::vector<PolyVec> cs; PolyVec gs, tp; std::vector<PolyVec> ts; PolyVec u; };
+template <size_t N>
+struct SumProofVerificationContext { SumProofCommitment<N> cm; Poly d; };
+struct SumProofChallenge { Poly d; };
+struct SumProofResponse { PolyVec zp; std::vector<PolyVec> zs; };
+
+template <size_t N>
+class SumProofProver {
+ public:
+  explicit SumProofProver(const CommitmentKey<N>& ck) : ck_(ck) {}
+  // sum.rs:99-178.  The commitments use the host sampler per commitment (like the reference); the
+  // algebra of xp, ts, tp, u is one call into the fused batch entry point with the sampled randomness.
+  std::pair<SumProofResponseContext<N>, SumProofCommitment<N>> commit(Rng& rng, const PolyVec& gs,
+                                                                    const std::vector<PolyVec>& xs) const {
+    const auto& be = ck_.backend();
+    const Params& P = be->params;
+    if (gs.empty() || gs.size() != xs.size()) throw std::runtime_error("commit: gs empty or gs.len() != xs.len() (sum.rs:105)");
+    const size_t V = gs.size();
+    for (const Poly& gi : gs)
+      if (gi.size() > N) throw std::runtime_error("polynomial longer than the ring degree");
+    auto sample_r = [&]() {
+      for (;;) {
+        PolyVec r;
+        for (size_t i = 0; i < P.k; ++i) r.push_back(random_polynomial_within<N>(rng, (int64_t)P.b));
+        std::vector<int64_t> rf;
+        flatten(r, N, rf);
+        uint8_t ok = 0;
+        be->check(rzk_norm2_le_batch(be->ctx(), rf.data(), (uint32_t)P.k, rzk_commit_bound(be->ctx()), &ok, 1));
+        if (ok) return r;
+      }
+    };
+    PolyVec rp = sample_r();
+    std::vector<PolyVec> rs;
+    for (size_t i = 0; i < V; ++i) rs.push_back(sample_r());
+    const double sd = (double)P.standard_deviation(N);
+    std::vector<PolyVec> ys(V);
+    for (auto& y : ys)
+      for (size_t i = 0; i < P.k; ++i) y.push_back(random_polynomial_in_normal_distribution<N>(rng, 0.0, sd));
+    PolyVec yp;
+    for (size_t i = 0; i < P.k; ++i) yp.push_back(random_polynomial_in_normal_distribution<N>(rng, 0.0, sd));
+    std::vector<int64_t> gsf, xsf, rsf, rpf, ysf, ypf;
+    flatten(gs, N, gsf);
+    for (const auto& x : xs) {
+      if (x.size() != P.l) throw std::runtime_error("commit: x_i.len() != l");
+      flatten(x, N, xsf);
+    }
+    for (const auto& r : rs) flatten(r, N, rsf);
+    flatten(rp, N, rpf);
+    for (const auto& y : ys) flatten(y, N, ysf);
+    flatten(yp, N, ypf);
+    const size_t nl = P.n + P.l;
+    std::vector<int64_t> csf(V * nl * N), cpf(nl * N), tsf(V * P.n * N), tpf(P.n * N), uf(P.l * N);
+    uint8_t ok = 0;
+    be->check(rzk_sum_commit_batch(be->ctx(), (uint32_t)V, gsf.data(), xsf.data(), rsf.data(), rpf.data(), ysf.data(),
+                                   ypf.data(), csf.data(), cpf.data(), tsf.data(), tpf.data(), uf.data(), &ok, 1));
+    SumProofResponseContext<N> rc;
+    SumProofCommitment<N> cm;
+    // xp is not revealed by the fused call; recompute it for the opening of cp from the Mat primitives
+    std::vector<int64_t> xpf(P.l * N, 0), tmp(P.l * N);
+    for (size_t i = 0; i < V; ++i) {
+      be->check(rzk_cmul_batch(be->ctx(), xsf.data() + i * P.l * N, (uint32_t)P.l, gsf.data() + i * N, tmp.data(), 1));
+      if (i == 0) xpf = tmp; else be->check(rzk_add_batch(be->ctx(), xpf.data(), tmp.data(), xpf.data(), P.l));
+    }
+    rc.opening_p = Opening<N>{unflatten(xpf, N), rp};
+    for (size_t i = 0; i < V; ++i) rc.openings.push_back(Opening<N>{xs[i], rs[i]});
+    rc.yp = yp;
+    rc.ys = ys;
+    cm.cp = unflatten(cpf, N);
+    cm.gs = gs;
+    cm.tp = unflatten(tpf, N);
+    cm.u = unflatten(uf, N);
+    for (size_t i = 0; i < V; ++i) {
+      cm.cs.push_back(unflatten(std::vector<int64_t>(csf.begin() + i * nl * N, csf.begin() + (i + 1) * nl * N), N));
+      cm.ts.push_back(unflatten(std::vector<int64_t>(tsf.begin() + i * P.n * N, tsf.begin() + (i + 1) * P.n * N), N));
+    }
+    return {rc, cm};
+  }
+  SumProofResponse create_response(const SumProofResponseContext<N>& ctx, const SumProofChallenge& ch) const {   // sum.rs:182-200
+    const auto& be = ck_.backend();
+    const Params& P = be->params;
+    const size_t V = ctx.ys.size();
+    std::vector<int64_t> ysf, ypf, rsf, rpf, zsf(V * P.k * N), zpf(P.k * N);
+    for (const auto& y : ctx.ys) flatten(y, N, ysf);
+    flatten(ctx.yp, N, ypf);
+    for (const auto& o : ctx.openings) flatten(o.r, N, rsf);
+    flatten(ctx.opening_p.r, N, rpf);
+    be->check(rzk_sum_response_batch(be->ctx(), (uint32_t)V, ysf.data(), ypf.data(), rsf.data(), rpf.data(), ch.d.data(),
+                                     zsf.data(), zpf.data(), 1));
+    SumProofResponse r;
+    r.zp = unflatten(zpf, N);
+    for (size_t i = 0; i < V; ++i)
+      r.zs.push_back(unflatten(std::vector<int64_t>(zsf.begin() + i * P.k * N, zsf.begin() + (i + 1) * P.k * N), N));
+    return r;
+  }
+
+ private:
+  const CommitmentKey<N>& ck_;
+};
+
+template <size_t N>
+class SumProofVerifier {
+ public:
+  explicit SumProofVerifier(const CommitmentKey<N>& ck) : ck_(ck) {}
+  std::pair<SumProofVerificationContext<N>, SumProofChallenge> generate_challenge(Rng& rng,
+                                                                                  const SumProofCommitment<N>& cm) const {
+    Poly d = random_polynomial_from_challenge_set<N>(rng, ck_.backend()->params.kappa);   // sum.rs:228-253
+    return {SumProofVerificationContext<N>{cm, d}, SumProofChallenge{d}};
+  }
+  bool verify(const SumProofResponse& r, const SumProofVerificationContext<N>& v) const {   // sum.rs:257-320
+    const auto& be = ck_.backend();
+    const size_t V = r.zs.size();
+    // sum.rs:273 rejects only when BOTH lengths differ (Q4); the dense ABI needs equal lengths, so
+    // any length mismatch is a rejection here.
+    if (V == 0 || V != v.cm.ts.size() || V != v.cm.cs.size() || V != v.cm.gs.size()) return false;
+    std::vector<int64_t> zsf, zpf, csf, cpf, gsf, tsf, tpf, uf;
+    for (const auto& z : r.zs) flatten(z, N, zsf);
+    flatten(r.zp, N, zpf);
+    for (const auto& c : v.cm.cs) flatten(c, N, csf);
+    flatten(v.cm.cp, N, cpf);
+    flatten(v.cm.gs, N, gsf);
+    for (const auto& t : v.cm.ts) flatten(t, N, tsf);
+    flatten(v.cm.tp, N, tpf);
+    flatten(v.cm.u, N, uf);
+    uint8_t acc = 0;
+    be->check(rzk_sum_verify_batch(be->ctx(), (uint32_t)V, zsf.data(), zpf.data(), csf.data(), cpf.data(), gsf.data(),
+                                   tsf.data(), tpf.data(), uf.data(), v.d.data(), &acc, 1));
+    return acc != 0;
+  }
+
+ private:
+  const CommitmentKey<N>& ck_;
+};
+
+}  // namespace ring_zk

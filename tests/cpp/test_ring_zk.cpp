@@ -1,0 +1,156 @@
+// C++ mirror of the reference's integration tests (tests/test.rs:11-93): for each proof type, random
+// (ck, x[, g]) over many iterations with a fresh key each time; assert Commitment::verify and the
+// protocol's verify return true; plus the negative checks the reference has in its doctests
+// (commit.rs:169-170: a mismatched opening is rejected) and a tampered response per proof type.
+// Runs on the GPU through ring_zk_amd/host/ring_zk.hpp -> librzk_hip.so.
+//
+// build: g++ -O2 -std=c++17 tests/cpp/test_ring_zk.cpp -Lring_zk_amd -lrzk_hip -Wl,-rpath,$PWD/ring_zk_amd -o /tmp/test_ring_zk
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../ring_zk_amd/host/ring_zk.hpp"
+
+using namespace ring_zk;
+
+#ifndef TEST_N
+#define TEST_N 512
+#endif
+constexpr size_t N = TEST_N;   // the reference uses N = 16 (tests/test.rs:8); the kernels start at 512
+
+#define REQUIRE(cond)                                                       \
+  do {                                                                      \
+    if (!(cond)) {                                                          \
+      std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+      std::exit(1);                                                         \
+    }                                                                       \
+  } while (0)
+
+// tests/test.rs:95-99: coefficients uniform in [-bound, bound], random length 1..=N (shorter = trimmed)
+static Poly random_value(Rng& rng, int64_t bound) {
+  Poly p = random_polynomial_within<N>(rng, bound);
+  std::uniform_int_distribution<size_t> len(1, N);
+  p.resize(len(rng));
+  return p;
+}
+
+static void test_open_proof(int iters) {
+  Rng rng(1);
+  Params params;
+  auto be = std::make_shared<Backend<N>>(params);
+  for (int it = 0; it < iters; ++it) {
+    CommitmentKey<N> ck(rng, be);
+    PolyVec x = {random_value(rng, params.q)};
+    OpenProofProver<N> prover(ck);
+    OpenProofVerifier<N> verifier(ck);
+    auto [rctx, cm] = prover.commit(rng, x);
+    REQUIRE(commitment_verify(cm.c, rctx.opening, ck));
+    auto [vctx, ch] = verifier.generate_challenge(rng, cm);
+    auto resp = prover.create_response(rctx, ch);
+    REQUIRE(verifier.verify(resp, vctx));
+    if (it < 3) {
+      auto bad = resp;
+      bad.z[1][it] += 1;
+      REQUIRE(!verifier.verify(bad, vctx));
+      Opening<N> wrong = rctx.opening;          // commit.rs:169-170: mismatched opening is rejected
+      wrong.x[0][0] += wrong.x[0][0] > 0 ? -1 : 1;
+      REQUIRE(!commitment_verify(cm.c, wrong, ck));
+    }
+  }
+  std::printf("test_open_proof ok (%d iterations, N=%zu)\n", iters, N);
+}
+
+static void test_linear_proof(int iters) {
+  Rng rng(2);
+  Params params;
+  auto be = std::make_shared<Backend<N>>(params);
+  for (int it = 0; it < iters; ++it) {
+    CommitmentKey<N> ck(rng, be);
+    PolyVec x = {random_value(rng, params.q)};
+    Poly g = random_value(rng, params.q);
+    g.resize(N, 0);
+    LinearProofProver<N> prover(ck);
+    LinearProofVerifier<N> verifier(ck);
+    auto [rctx, cm] = prover.commit(rng, g, x);
+    REQUIRE(commitment_verify(cm.c, rctx.opening, ck));
+    REQUIRE(commitment_verify(cm.cp, rctx.opening_p, ck));
+    auto [vctx, ch] = verifier.generate_challenge(rng, cm);
+    auto resp = prover.create_response(rctx, ch);
+    REQUIRE(verifier.verify(resp, vctx));
+    if (it < 3) {
+      auto bad = resp;
+      bad.zp[2][7] -= 1;
+      REQUIRE(!verifier.verify(bad, vctx));
+    }
+  }
+  std::printf("test_linear_proof ok (%d iterations)\n", iters);
+}
+
+static void test_sum_proof(int iters) {
+  Rng rng(3);
+  Params params;
+  constexpr size_t VL = 4;   // tests/test.rs:65
+  auto be = std::make_shared<Backend<N>>(params);
+  for (int it = 0; it < iters; ++it) {
+    CommitmentKey<N> ck(rng, be);
+    std::vector<PolyVec> xs;
+    PolyVec gs;
+    for (size_t i = 0; i < VL; ++i) xs.push_back({random_value(rng, params.q)});
+    for (size_t i = 0; i < VL; ++i) {
+      Poly g = random_value(rng, params.q);
+      g.resize(N, 0);
+      gs.push_back(g);
+    }
+    SumProofProver<N> prover(ck);
+    SumProofVerifier<N> verifier(ck);
+    auto [rctx, cm] = prover.commit(rng, gs, xs);
+    REQUIRE(commitment_verify(cm.cp, rctx.opening_p, ck));
+    for (size_t i = 0; i < VL; ++i) REQUIRE(commitment_verify(cm.cs[i], rctx.openings[i], ck));
+    auto [vctx, ch] = verifier.generate_challenge(rng, cm);
+    auto resp = prover.create_response(rctx, ch);
+    REQUIRE(verifier.verify(resp, vctx));
+    if (it < 3) {
+      auto bad = resp;
+      bad.zs[VL - 1][0][3] += 2;
+      REQUIRE(!verifier.verify(bad, vctx));
+      auto shorter = resp;
+      shorter.zs.pop_back();
+      REQUIRE(!verifier.verify(shorter, vctx));
+    }
+  }
+  std::printf("test_sum_proof ok (%d iterations, VL=%zu)\n", iters, VL);
+}
+
+static void test_panics() {
+  Rng rng(4);
+  Params params;
+  auto be = std::make_shared<Backend<N>>(params);
+  CommitmentKey<N> ck(rng, be);
+  OpenProofProver<N> prover(ck);
+  bool threw = false;
+  try {
+    prover.commit(rng, PolyVec{});   // commit.rs:95: assert_eq!(l, x.len())
+  } catch (const std::runtime_error&) {
+    threw = true;
+  }
+  REQUIRE(threw);
+  threw = false;
+  try {
+    Params bad;
+    bad.n = 3;   // k > n violated
+    Backend<N> b2(bad);
+  } catch (const std::runtime_error&) {
+    threw = true;
+  }
+  REQUIRE(threw);
+  std::printf("test_panics ok\n");
+}
+
+int main(int argc, char** argv) {
+  const int iters = argc > 1 ? std::atoi(argv[1]) : 100;   // tests/test.rs: 100 iterations each
+  test_open_proof(iters);
+  test_linear_proof(iters);
+  test_sum_proof(iters);
+  test_panics();
+  std::printf("all ok\n");
+  return 0;
+}

@@ -159,6 +159,19 @@ def main():
         us, launches = ctx.prof_read()
         ctx.prof_enable(False)
         avg_us = us / max(launches, 1)
+        # per-phase wall time (all launches of a phase), events on the stream the kernels run on
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(psteps)]
+        for i in range(psteps):
+            evs[i][0].record()
+            c_, t_, _ok = ctx.open_commit(x, r, y)
+            evs[i][1].record()
+            z_ = ctx.open_response(y, r, d)
+            evs[i][2].record()
+            ctx.open_verify(z_, t_, c_, d)
+            evs[i][3].record()
+        torch.cuda.synchronize()
+        phase_us = {name: sum(evs[i][j].elapsed_time(evs[i][j + 1]) for i in range(psteps)) / psteps * 1e3
+                    for j, name in enumerate(("commit", "response", "verify"))}
         # algorithmic bytes of one OpenProof cycle at the boundary, key resident:
         # commit 7 in + 3 out, response 7 in + 3 out, verify 6 in = 26 polynomials of 8*N bytes
         cycle_bytes = 26 * 8 * N * B
@@ -180,6 +193,7 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
             "avg_launch_us": avg_us,
+            "phase_us": phase_us,
             "launches_timed": int(launches),
             "algorithmic_bytes_per_launch": per_launch,
         }

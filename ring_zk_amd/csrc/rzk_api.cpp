@@ -65,6 +65,7 @@ struct rzk_ctx {
   DevTables hT{};
   DevTables* dT = nullptr;
   uint32_t* d_tw = nullptr;
+  uint32_t* d_row_scratch = nullptr;   // per-wave Garner state of the row kernel (third prime only)
   // key
   bool key_loaded = false;
   std::vector<uint8_t> key_class;     // (n+l)*k
@@ -414,7 +415,7 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
     HIPCHK(c, hipEventRecord(e0, c->stream));
   }
   int lrc = launch_row_program((int)c->logn, cfg_of(c), dp.d, dp.nrows, dp.has_vec, ops, c->d_key_ntt,
-                               c->d_key_inf, c->dT, c->d_tw, flags, batch);
+                               c->d_key_inf, c->dT, c->d_tw, c->d_row_scratch, flags, batch);
   if (lrc == -2) return fail(c, RZK_E_UNSUPPORTED, "batch * rows must stay below 2^32");
   if (lrc != 0) {
     c->err = std::string("row kernel launch: ") + (lrc > 0 ? hipGetErrorString((hipError_t)lrc) : "bad ring degree");
@@ -538,6 +539,8 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
              hipMemcpy(c->d_tw, all.data(), all.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
   c->hT.cap[0] = 0.0;
   for (int np = 1; np <= kMaxPrimes; ++np) c->hT.cap[np] = host::crt_capacity(np);
+  okk = okk && hipMalloc((void**)&c->d_row_scratch, row_scratch_words((int)c->logn, c->num_cus) * sizeof(uint32_t)) ==
+                   hipSuccess;
   okk = okk && hipMalloc((void**)&c->dT, sizeof(DevTables)) == hipSuccess &&
         hipMemcpy(c->dT, &c->hT, sizeof(DevTables), hipMemcpyHostToDevice) == hipSuccess;
   if (!okk) {
@@ -563,6 +566,7 @@ void rzk_ctx_destroy(rzk_ctx* c) {
   if (c->stage.p) (void)hipFree(c->stage.p);
   if (c->dT) (void)hipFree(c->dT);
   if (c->d_tw) (void)hipFree(c->d_tw);
+  if (c->d_row_scratch) (void)hipFree(c->d_row_scratch);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }

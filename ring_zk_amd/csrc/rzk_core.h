@@ -33,6 +33,22 @@
 #define RZK_HD inline
 #endif
 
+// Optional scheduling fence for the device build (tuning knob, off by default): VALU instructions may
+// not be moved across it (loads, LDS reads and scalar instructions may); placed after every
+// RZK_BFLY_GROUP butterflies.
+#ifndef RZK_BFLY_GROUP
+#define RZK_BFLY_GROUP 0   // 0 = no fence (measured: fences do not lower the register count)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RZK_SCHED_GROUP(count)                                                          \
+  do {                                                                                  \
+    if (RZK_BFLY_GROUP > 0 && ((count) % (RZK_BFLY_GROUP > 0 ? RZK_BFLY_GROUP : 1)) == 0) \
+      __builtin_amdgcn_sched_barrier(0x4 | 0x20 | 0x100);                               \
+  } while (0)
+#else
+#define RZK_SCHED_GROUP(count) do { } while (0)
+#endif
+
 namespace rzk {
 
 constexpr int kMaxPrimes = 3;
@@ -112,43 +128,58 @@ struct Geo {
 };
 
 // ---- LDS transpositions -----------------------------------------------------------------------------
+// Every access is written as (per-lane base) + (compile-time offset), so the compiler folds the offset
+// into the DS instruction and needs ONE address register per pattern.  With j = base_j + const and the
+// pad term j >> 5, the split is exact because the lane part and the constant part never carry into
+// each other below bit 5:
+//   phase 1: j = e*64 + lane          -> addr = [lane + (lane>>5)] + e*66
+//   phase 2: j = hi*64 + (r<<LOSH)+lo -> addr = [hi*66 + lo] + (r<<LOSH) + ((r<<LOSH)>>5)     (lo < 2^LOSH)
+//   phase 3: j = lane*E + c           -> addr = [lane*E + ((lane*E)>>5)] + c                  ((lane*E & 31) + c < 32)
+template <int LOGN>
+struct LdsMap {
+  using G = Geo<LOGN>;
+  RZK_HD static int base_p1(int lane) { return lane + (lane >> 5); }
+  static constexpr int off_p1(int e) { return e * 66; }
+  RZK_HD static int base_p2(int lane) { return G::p2_hi(lane) * 66 + G::p2_lo(lane); }
+  static constexpr int off_p2(int r) { return (r << G::LOSH) + ((r << G::LOSH) >> 5); }
+  RZK_HD static int base_p3(int lane) { return lane * G::E + ((lane * G::E) >> 5); }
+  static constexpr int off_p3(int c) { return c; }
+};
 template <int LOGN>
 RZK_HD void lds_put_p1(const uint32_t* x, int lane, uint32_t* lds) {
-  using G = Geo<LOGN>;
+  uint32_t* p = lds + LdsMap<LOGN>::base_p1(lane);
 #pragma unroll
-  for (int e = 0; e < G::E; ++e) lds[G::lds_addr(G::j_p1(lane, e))] = x[e];
+  for (int e = 0; e < Geo<LOGN>::E; ++e) p[LdsMap<LOGN>::off_p1(e)] = x[e];
 }
 template <int LOGN>
 RZK_HD void lds_get_p1(uint32_t* x, int lane, const uint32_t* lds) {
-  using G = Geo<LOGN>;
+  const uint32_t* p = lds + LdsMap<LOGN>::base_p1(lane);
 #pragma unroll
-  for (int e = 0; e < G::E; ++e) x[e] = lds[G::lds_addr(G::j_p1(lane, e))];
+  for (int e = 0; e < Geo<LOGN>::E; ++e) x[e] = p[LdsMap<LOGN>::off_p1(e)];
 }
 template <int LOGN>
 RZK_HD void lds_put_p2(const uint32_t* x, int lane, uint32_t* lds) {
-  using G = Geo<LOGN>;
-  const int base = G::p2_hi(lane) * 64 + G::p2_lo(lane);
+  uint32_t* p = lds + LdsMap<LOGN>::base_p2(lane);
 #pragma unroll
-  for (int r = 0; r < G::E; ++r) lds[G::lds_addr(base + (r << G::LOSH))] = x[r];
+  for (int r = 0; r < Geo<LOGN>::E; ++r) p[LdsMap<LOGN>::off_p2(r)] = x[r];
 }
 template <int LOGN>
 RZK_HD void lds_get_p2(uint32_t* x, int lane, const uint32_t* lds) {
-  using G = Geo<LOGN>;
-  const int base = G::p2_hi(lane) * 64 + G::p2_lo(lane);
+  const uint32_t* p = lds + LdsMap<LOGN>::base_p2(lane);
 #pragma unroll
-  for (int r = 0; r < G::E; ++r) x[r] = lds[G::lds_addr(base + (r << G::LOSH))];
+  for (int r = 0; r < Geo<LOGN>::E; ++r) x[r] = p[LdsMap<LOGN>::off_p2(r)];
 }
 template <int LOGN>
 RZK_HD void lds_put_p3(const uint32_t* x, int lane, uint32_t* lds) {
-  using G = Geo<LOGN>;
+  uint32_t* p = lds + LdsMap<LOGN>::base_p3(lane);
 #pragma unroll
-  for (int c = 0; c < G::E; ++c) lds[G::lds_addr(G::j_p3(lane, c))] = x[c];
+  for (int c = 0; c < Geo<LOGN>::E; ++c) p[LdsMap<LOGN>::off_p3(c)] = x[c];
 }
 template <int LOGN>
 RZK_HD void lds_get_p3(uint32_t* x, int lane, const uint32_t* lds) {
-  using G = Geo<LOGN>;
+  const uint32_t* p = lds + LdsMap<LOGN>::base_p3(lane);
 #pragma unroll
-  for (int c = 0; c < G::E; ++c) x[c] = lds[G::lds_addr(G::j_p3(lane, c))];
+  for (int c = 0; c < Geo<LOGN>::E; ++c) x[c] = p[LdsMap<LOGN>::off_p3(c)];
 }
 
 // ---- forward transform, register phases ----------------------------------------------------------------
@@ -156,6 +187,8 @@ RZK_HD void lds_get_p3(uint32_t* x, int lane, const uint32_t* lds) {
 template <int LOGN>
 RZK_HD void fwd_phase1(uint32_t* x, const uint32_t* tw, const PrimeConsts& pc) {
   using G = Geo<LOGN>;
+  int nb = 0;
+  (void)nb;
 #pragma unroll
   for (int s = 0; s < G::LE; ++s) {
     const int half = G::E >> (s + 1);
@@ -164,12 +197,16 @@ RZK_HD void fwd_phase1(uint32_t* x, const uint32_t* tw, const PrimeConsts& pc) {
       if (e & half) continue;
       const uint32_t w = tw[(1 << s) + (e >> (G::LE - s))];   // wave-uniform
       bfly_fwd(x[e], x[e + half], w, pc);
+      ++nb;
+      RZK_SCHED_GROUP(nb);
     }
   }
 }
 template <int LOGN>
 RZK_HD void fwd_phase2(uint32_t* x, int lane, const uint32_t* tw, const PrimeConsts& pc) {
   using G = Geo<LOGN>;
+  int nb = 0;
+  (void)nb;
   const int hi = G::p2_hi(lane);
 #pragma unroll
   for (int sp = 0; sp < G::LE; ++sp) {
@@ -179,12 +216,16 @@ RZK_HD void fwd_phase2(uint32_t* x, int lane, const uint32_t* tw, const PrimeCon
     for (int r = 0; r < G::E; ++r) {
       if (r & half) continue;
       bfly_fwd(x[r], x[r + half], twl[r >> (G::LE - sp)], pc);
+      ++nb;
+      RZK_SCHED_GROUP(nb);
     }
   }
 }
 template <int LOGN>
 RZK_HD void fwd_phase3(uint32_t* x, int lane, const uint32_t* tw, const PrimeConsts& pc) {
   using G = Geo<LOGN>;
+  int nb = 0;
+  (void)nb;
 #pragma unroll
   for (int sq = 0; sq < G::R3; ++sq) {
     const int sh = G::R3 - sq;            // idx = 2^s + (j >> sh)
@@ -194,6 +235,8 @@ RZK_HD void fwd_phase3(uint32_t* x, int lane, const uint32_t* tw, const PrimeCon
     for (int c = 0; c < G::E; ++c) {
       if (c & half) continue;
       bfly_fwd(x[c], x[c + half], twl[c >> sh], pc);
+      ++nb;
+      RZK_SCHED_GROUP(nb);
     }
   }
 }
@@ -202,6 +245,8 @@ RZK_HD void fwd_phase3(uint32_t* x, int lane, const uint32_t* tw, const PrimeCon
 template <int LOGN>
 RZK_HD void inv_phase3(uint32_t* x, int lane, const uint32_t* tw, const PrimeConsts& pc) {
   using G = Geo<LOGN>;
+  int nb = 0;
+  (void)nb;
 #pragma unroll
   for (int sq = G::R3 - 1; sq >= 0; --sq) {
     const int sh = G::R3 - sq;
@@ -211,12 +256,16 @@ RZK_HD void inv_phase3(uint32_t* x, int lane, const uint32_t* tw, const PrimeCon
     for (int c = 0; c < G::E; ++c) {
       if (c & half) continue;
       bfly_inv(x[c], x[c + half], twl[c >> sh], pc);
+      ++nb;
+      RZK_SCHED_GROUP(nb);
     }
   }
 }
 template <int LOGN>
 RZK_HD void inv_phase2(uint32_t* x, int lane, const uint32_t* tw, const PrimeConsts& pc) {
   using G = Geo<LOGN>;
+  int nb = 0;
+  (void)nb;
   const int hi = G::p2_hi(lane);
 #pragma unroll
   for (int sp = G::LE - 1; sp >= 0; --sp) {
@@ -226,12 +275,16 @@ RZK_HD void inv_phase2(uint32_t* x, int lane, const uint32_t* tw, const PrimeCon
     for (int r = 0; r < G::E; ++r) {
       if (r & half) continue;
       bfly_inv(x[r], x[r + half], twl[r >> (G::LE - sp)], pc);
+      ++nb;
+      RZK_SCHED_GROUP(nb);
     }
   }
 }
 template <int LOGN>
 RZK_HD void inv_phase1(uint32_t* x, const uint32_t* tw, const PrimeConsts& pc) {
   using G = Geo<LOGN>;
+  int nb = 0;
+  (void)nb;
 #pragma unroll
   for (int s = G::LE - 1; s >= 0; --s) {
     const int half = G::E >> (s + 1);
@@ -240,6 +293,8 @@ RZK_HD void inv_phase1(uint32_t* x, const uint32_t* tw, const PrimeConsts& pc) {
       if (e & half) continue;
       const uint32_t w = tw[(1 << s) + (e >> (G::LE - s))];
       bfly_inv(x[e], x[e + half], w, pc);
+      ++nb;
+      RZK_SCHED_GROUP(nb);
     }
   }
 }
@@ -339,17 +394,27 @@ RZK_HD uint32_t to_zq(int64_t s, const CrtConsts& C) {   // s in (-q, 2q) -> [0,
   s = s >= (int64_t)C.q ? s - (int64_t)C.q : s;
   return (uint32_t)s;
 }
+// second digit d1 = (X' mod p1 - d0) * p0^{-1} mod p1 from the prime-1 residue r and d0
+RZK_HD uint32_t crt_digit1(uint32_t r, uint32_t d0, int np, const PrimeConsts* pc, const CrtConsts& C) {
+  const uint32_t a1 = csub(csub(r + C.hmod[np][1], pc[1].twop), pc[1].p);
+  const uint32_t t1 = a1 + pc[1].p - csub(d0, pc[1].p);                      // (0, 2p1)
+  return csub(mont_lazy(t1, C.inv01_r, pc[1].p, pc[1].npinv), pc[1].p);
+}
+// (d0 + d1 p0) mod q in [0,q)
+RZK_HD uint32_t crt_value01_modq(uint32_t d0, uint32_t d1, const CrtConsts& C) {
+  return to_zq((int64_t)d0 + montq(d1, C.c1, C), C);
+}
+// (d0 + d1 p0) mod p2, lazy [0,2p2) — only needed when a third prime follows
+RZK_HD uint32_t crt_value01_modp2(uint32_t d0, uint32_t d1, const PrimeConsts* pc, const CrtConsts& C) {
+  const uint32_t m1 = mont_lazy(d1, C.p0_mod_p2_r, pc[2].p, pc[2].npinv);    // d1*p0 mod p2, [0,2p2)
+  return csub(csub(d0, pc[2].p) + m1, pc[2].twop);
+}
 RZK_HD void crt_fold1(uint32_t r, int np, const PrimeConsts* pc, const CrtConsts& C, uint32_t& stA,
                       uint32_t& stB) {
   const uint32_t d0 = stA;
-  const uint32_t a1 = csub(csub(r + C.hmod[np][1], pc[1].twop), pc[1].p);
-  const uint32_t t1 = a1 + pc[1].p - csub(d0, pc[1].p);                      // (0, 2p1)
-  const uint32_t d1 = csub(mont_lazy(t1, C.inv01_r, pc[1].p, pc[1].npinv), pc[1].p);
-  stA = to_zq((int64_t)d0 + montq(d1, C.c1, C), C);
-  if (np == 3) {
-    const uint32_t m1 = mont_lazy(d1, C.p0_mod_p2_r, pc[2].p, pc[2].npinv);  // d1*p0 mod p2, [0,2p2)
-    stB = csub(csub(d0, pc[2].p) + m1, pc[2].twop);                          // (d0 + d1 p0) mod p2, [0,2p2)
-  }
+  const uint32_t d1 = crt_digit1(r, d0, np, pc, C);
+  stA = crt_value01_modq(d0, d1, C);
+  if (np == 3) stB = crt_value01_modp2(d0, d1, pc, C);
 }
 RZK_HD void crt_fold2(uint32_t r, const PrimeConsts* pc, const CrtConsts& C, uint32_t& stA, uint32_t stB) {
   const uint32_t a2 = csub(csub(r + C.hmod[3][2], pc[2].twop), pc[2].p);

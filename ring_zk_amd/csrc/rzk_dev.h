@@ -78,7 +78,10 @@ struct LaunchCfg {
 
 int launch_row_program(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows, bool has_vec,
                        const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf,
-                       const DevTables* d_T, const uint32_t* d_tw, uint8_t* d_flags, uint64_t batch);
+                       const DevTables* d_T, const uint32_t* d_tw, uint32_t* d_scratch, uint8_t* d_flags,
+                       uint64_t batch);
+// words of per-wave global scratch the row kernel needs: (max blocks) * 4 waves * N
+size_t row_scratch_words(int logn, int num_cus);
 int launch_key_transform(int logn, const LaunchCfg& cfg, const int64_t* d_key, uint32_t entries,
                          uint32_t* d_key_ntt, const DevTables* d_T, const uint32_t* d_tw);
 int launch_ntt(int logn, bool inverse, const LaunchCfg& cfg, int prime, const uint32_t* d_in,

@@ -80,15 +80,38 @@ __device__ __forceinline__ const int64_t* operand_ptr(const Operands& ops, uint3
   return ops.base[op] + ((uint64_t)idx * ops.stride[op] + off) * (uint64_t)n_coef;
 }
 
+#ifndef RZK_LOAD_LO32
+#define RZK_LOAD_LO32 0   // 1: fetch only the low dword of each int64 coefficient (measured: no gain)
+#endif
+#ifndef RZK_EPI_CHUNK
+#define RZK_EPI_CHUNK 16  // coefficients per lane handled together in the epilogue (4 was slower: fewer loads in flight)
+#endif
+#ifndef RZK_OPAQUE_LANE
+#define RZK_OPAQUE_LANE 0   // 1: recompute lane-dependent addresses per term (fewer VGPRs, more ALU; measured: no gain)
+#endif
+#if RZK_OPAQUE_LANE
+#define RZK_OPAQUE(v) asm volatile("" : "+v"(v))
+#else
+#define RZK_OPAQUE(v) do { } while (0)
+#endif
+
 // Load one coefficient polynomial (coalesced phase-1 layout), lift it into prime field `pc` and,
 // on the first prime pass, also return its 1-norm and max-norm (wave-uniform).
 template <int LOGN>
 __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict__ src, int lane,
                                           const PrimeConsts& pc, bool want_norms, double& l1, double& linf) {
   using G = Geo<LOGN>;
+  // centred coefficients fit 32 bits: fetch only the low dword of every int64 (same cache lines,
+  // half the registers and half the data returned to the wave)
   int32_t v[G::E];
+#if RZK_LOAD_LO32
+  const int32_t* __restrict__ lo = reinterpret_cast<const int32_t*>(src);
+#pragma unroll
+  for (int e = 0; e < G::E; ++e) v[e] = lo[2 * G::j_p1(lane, e)];
+#else
 #pragma unroll
   for (int e = 0; e < G::E; ++e) v[e] = (int32_t)src[G::j_p1(lane, e)];
+#endif
   if (want_norms) {
     uint64_t sum = 0;
     uint32_t mx = 0;
@@ -124,14 +147,17 @@ template <int LOGN, bool HAS_VEC>
 __global__ void __launch_bounds__(256, RZK_ROW_MIN_WAVES)
 row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t* __restrict__ key_ntt,
            const double* __restrict__ key_inf, const DevTables* __restrict__ Tp,
-           const uint32_t* __restrict__ tw_all, uint8_t* __restrict__ flags, const uint32_t ntasks) {
+           const uint32_t* __restrict__ tw_all, uint32_t* __restrict__ scratch, uint8_t* __restrict__ flags,
+           const uint32_t ntasks) {
   using G = Geo<LOGN>;
   constexpr int E = G::E;
   constexpr int N = G::N;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  uint32_t* lds = smem + wave * G::LDS_WORDS;
+  uint32_t* lds = smem + wave * G::LDS_WORDS;               // transposition slab
+  uint32_t* st_lds = smem + 4 * G::LDS_WORDS + wave * N;    // Garner state A (one word per coefficient)
+  uint32_t* st_glb = scratch + ((size_t)blockIdx.x * 4 + wave) * N;   // state B, only touched when np == 3
   const DevTables& T = *Tp;
   const uint32_t nrows = prog->nrows;
 
@@ -141,12 +167,9 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
     const uint32_t bo = ops.group > 1 ? b / ops.group : b;
     const Row row = prog->rows[rowi];
 
-    int64_t s[E];
-    if (row.nterms > 0) {
-      uint32_t stA[E], stB[E];
-#pragma unroll
-      for (int e = 0; e < E; ++e) stA[e] = stB[e] = 0;
-      int np = kMaxPrimes;
+    const bool has_terms = row.nterms > 0;
+    int np = kMaxPrimes;
+    if (has_terms) {
       double bound = 0.0;
 #pragma unroll 1
       for (int pi = 0; pi < np; ++pi) {
@@ -160,18 +183,21 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
 #pragma unroll 1
         for (uint32_t t = 0; t < row.nterms; ++t) {
           const Term tm = prog->terms[row.term0 + t];
+          // optional opaque copy of the lane id (RZK_OPAQUE_LANE): stops hoisting of lane-dependent addresses
+          int ln = lane;
+          RZK_OPAQUE(ln);
           uint32_t x[E];
           double l1b = 0, infb = 0;
-          load_lift<LOGN>(x, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane, pc, first, l1b, infb);
-          wave_fwd<LOGN>(x, lane, lds, twf, pc);
+          load_lift<LOGN>(x, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), ln, pc, first, l1b, infb);
+          wave_fwd<LOGN>(x, ln, lds, twf, pc);
           if (HAS_VEC && tm.kind == TERM_VEC) {
             // product of two per-proof polynomials: fold N^-1 and the Montgomery factor into one of them
             uint32_t xb[E];
 #pragma unroll
             for (int c = 0; c < E; ++c) xb[c] = csub(mont_lazy(x[c], pc.ninv_r2, pc.p, pc.npinv), pc.p);
             double l1a = 0, infa = 0;
-            load_lift<LOGN>(x, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), lane, pc, first, l1a, infa);
-            wave_fwd<LOGN>(x, lane, lds, twf, pc);
+            load_lift<LOGN>(x, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), ln, pc, first, l1a, infa);
+            wave_fwd<LOGN>(x, ln, lds, twf, pc);
             if (first) {
               const double u = l1a * infb, v = infa * l1b;
               bound += u < v ? u : v;
@@ -190,7 +216,7 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
             if (tm.sign >= 0) {
 #pragma unroll
               for (int g = 0; g < E / 4; ++g) {
-                const uint4 kv = kp[g * 64 + lane];
+                const uint4 kv = kp[g * 64 + ln];
                 acc[4 * g + 0] = mac_add(acc[4 * g + 0], x[4 * g + 0], kv.x, pc);
                 acc[4 * g + 1] = mac_add(acc[4 * g + 1], x[4 * g + 1], kv.y, pc);
                 acc[4 * g + 2] = mac_add(acc[4 * g + 2], x[4 * g + 2], kv.z, pc);
@@ -199,7 +225,7 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
             } else {
 #pragma unroll
               for (int g = 0; g < E / 4; ++g) {
-                const uint4 kv = kp[g * 64 + lane];
+                const uint4 kv = kp[g * 64 + ln];
                 acc[4 * g + 0] = mac_sub(acc[4 * g + 0], x[4 * g + 0], kv.x, pc);
                 acc[4 * g + 1] = mac_sub(acc[4 * g + 1], x[4 * g + 1], kv.y, pc);
                 acc[4 * g + 2] = mac_sub(acc[4 * g + 2], x[4 * g + 2], kv.z, pc);
@@ -214,46 +240,72 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
           np = bound <= T.cap[1] ? 1 : (bound <= T.cap[2] ? 2 : 3);
           np = __builtin_amdgcn_readfirstlane(np);
         }
-        wave_inv<LOGN>(acc, lane, lds, twi, pc);
+        int li = lane;
+        RZK_OPAQUE(li);
+        wave_inv<LOGN>(acc, li, lds, twi, pc);
+        // fold this prime's residues into the Garner state: word A lives in LDS, word B (third prime
+        // only) in a per-wave global scratch line, so neither occupies registers during the transforms
         if (pi == 0) {
 #pragma unroll
-          for (int e = 0; e < E; ++e) stA[e] = crt_fold0(acc[e], np, T.pc, T.crt);
+          for (int e = 0; e < E; ++e) st_lds[G::j_p1(li, e)] = crt_fold0(acc[e], np, T.pc, T.crt);
         } else if (pi == 1) {
+          uint32_t d0[E];
 #pragma unroll
-          for (int e = 0; e < E; ++e) crt_fold1(acc[e], np, T.pc, T.crt, stA[e], stB[e]);
+          for (int e = 0; e < E; ++e) {
+            d0[e] = st_lds[G::j_p1(li, e)];
+            acc[e] = crt_digit1(acc[e], d0[e], np, T.pc, T.crt);
+          }
+          if (np == 3) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) st_glb[G::j_p1(li, e)] = crt_value01_modp2(d0[e], acc[e], T.pc, T.crt);
+          }
+#pragma unroll
+          for (int e = 0; e < E; ++e) st_lds[G::j_p1(li, e)] = crt_value01_modq(d0[e], acc[e], T.crt);
         } else {
 #pragma unroll
-          for (int e = 0; e < E; ++e) crt_fold2(acc[e], T.pc, T.crt, stA[e], stB[e]);
+          for (int e = 0; e < E; ++e) {
+            uint32_t a = st_lds[G::j_p1(li, e)];
+            crt_fold2(acc[e], T.pc, T.crt, a, st_glb[G::j_p1(li, e)]);
+            st_lds[G::j_p1(li, e)] = a;
+          }
         }
       }
-#pragma unroll
-      for (int e = 0; e < E; ++e) s[e] = crt_finish(stA[e], np, T.crt);
-    } else {
-#pragma unroll
-      for (int e = 0; e < E; ++e) s[e] = 0;
     }
 
-    // plain additions, then store / zero test
-#pragma unroll 1
-    for (uint32_t a = 0; a < row.nadds; ++a) {
-      const AddTerm ad = prog->adds[row.add0 + a];
-      const int64_t* __restrict__ src = operand_ptr(ops, ad.op, ad.off, b, bo, N);
-      if (ad.sign >= 0) {
+    // plain additions, then store / zero test — in chunks of four coefficients per lane so that only a
+    // few 64-bit values are live at a time
+    int nz = 0;
+    constexpr int CH = RZK_EPI_CHUNK < E ? RZK_EPI_CHUNK : E;
 #pragma unroll
-        for (int e = 0; e < E; ++e) s[e] = center_rounds<1>(s[e] + src[G::j_p1(lane, e)], T.crt);
+    for (int e0 = 0; e0 < E; e0 += CH) {
+      int64_t s4[CH];
+      if (has_terms) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) s4[i] = crt_finish(st_lds[G::j_p1(lane, e0 + i)], np, T.crt);
       } else {
 #pragma unroll
-        for (int e = 0; e < E; ++e) s[e] = center_rounds<1>(s[e] - src[G::j_p1(lane, e)], T.crt);
+        for (int i = 0; i < CH; ++i) s4[i] = 0;
+      }
+#pragma unroll 1
+      for (uint32_t a = 0; a < row.nadds; ++a) {
+        const AddTerm ad = prog->adds[row.add0 + a];
+        const int32_t* __restrict__ src =
+            reinterpret_cast<const int32_t*>(operand_ptr(ops, ad.op, ad.off, b, bo, N));
+        const int64_t sg = ad.sign >= 0 ? 1 : -1;
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+          s4[i] = center_rounds<1>(s4[i] + sg * (int64_t)src[2 * G::j_p1(lane, e0 + i)], T.crt);
+      }
+      if (row.mode == MODE_STORE) {
+        int64_t* __restrict__ dst = const_cast<int64_t*>(operand_ptr(ops, row.out_op, row.out_off, b, bo, N));
+#pragma unroll
+        for (int i = 0; i < CH; ++i) dst[G::j_p1(lane, e0 + i)] = s4[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) nz |= (s4[i] != 0);
       }
     }
-    if (row.mode == MODE_STORE) {
-      int64_t* __restrict__ dst = const_cast<int64_t*>(operand_ptr(ops, row.out_op, row.out_off, b, bo, N));
-#pragma unroll
-      for (int e = 0; e < E; ++e) dst[G::j_p1(lane, e)] = s[e];
-    } else {
-      int nz = 0;
-#pragma unroll
-      for (int e = 0; e < E; ++e) nz |= (s[e] != 0);
+    if (row.mode != MODE_STORE) {
       if (__any(nz) && lane == 0) flags[bo] = 0;
     }
   }
@@ -481,29 +533,32 @@ static inline unsigned grid_for(uint64_t tasks, int num_cus, int waves_per_block
     if (e_ != hipSuccess) return (int)e_;       \
   } while (0)
 
+size_t row_scratch_words(int logn, int num_cus) { return (size_t)num_cus * 8 * 4 * ((size_t)1 << logn); }
+
 template <int LOGN, bool HAS_VEC>
 static int launch_row_t(const LaunchCfg& cfg, const Program* d_prog, const Operands& ops,
                         const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T,
-                        const uint32_t* d_tw, uint8_t* d_flags, uint32_t ntasks) {
+                        const uint32_t* d_tw, uint32_t* d_scratch, uint8_t* d_flags, uint32_t ntasks) {
   using G = Geo<LOGN>;
-  const size_t lds = 4 * G::LDS_WORDS * sizeof(uint32_t);
-  const unsigned grid = grid_for(ntasks, cfg.num_cus);
+  const size_t lds = 4 * (G::LDS_WORDS + G::N) * sizeof(uint32_t);   // transposition slab + Garner state per wave
+  const unsigned grid = grid_for(ntasks, cfg.num_cus);               // <= num_cus * 8 blocks (scratch sizing)
   hipLaunchKernelGGL((row_kernel<LOGN, HAS_VEC>), dim3(grid), dim3(256), lds, (hipStream_t)cfg.stream, d_prog,
-                     ops, d_key_ntt, d_key_inf, T, d_tw, d_flags, ntasks);
+                     ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
   RZK_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_row_program(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows, bool has_vec,
                        const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf,
-                       const DevTables* T, const uint32_t* d_tw, uint8_t* d_flags, uint64_t batch) {
+                       const DevTables* T, const uint32_t* d_tw, uint32_t* d_scratch, uint8_t* d_flags,
+                       uint64_t batch) {
   if (batch == 0 || nrows == 0) return 0;
   if (batch * nrows >= (1ull << 32)) return -2;   // task index is 32-bit
   const uint32_t ntasks = (uint32_t)(batch * nrows);
-#define RZK_ROW_CASE(L)                                                                                      \
-  case L:                                                                                                    \
-    return has_vec ? launch_row_t<L, true>(cfg, d_prog, ops, d_key_ntt, d_key_inf, T, d_tw, d_flags, ntasks) \
-                   : launch_row_t<L, false>(cfg, d_prog, ops, d_key_ntt, d_key_inf, T, d_tw, d_flags, ntasks);
+#define RZK_ROW_CASE(L)                                                                                                 \
+  case L:                                                                                                               \
+    return has_vec ? launch_row_t<L, true>(cfg, d_prog, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks) \
+                   : launch_row_t<L, false>(cfg, d_prog, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
   switch (logn) {
     RZK_ROW_CASE(9)
     RZK_ROW_CASE(10)

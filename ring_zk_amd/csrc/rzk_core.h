@@ -389,10 +389,31 @@ RZK_HD int64_t crt_center(uint32_t r0, uint32_t r1, uint32_t r2, int np, const P
 RZK_HD uint32_t crt_fold0(uint32_t r, int np, const PrimeConsts* pc, const CrtConsts& C) {
   return csub(csub(r + C.hmod[np][0], pc[0].twop), pc[0].p);
 }
-RZK_HD uint32_t to_zq(int64_t s, const CrtConsts& C) {   // s in (-q, 2q) -> [0,q)
-  s = s < 0 ? s + (int64_t)C.q : s;
-  s = s >= (int64_t)C.q ? s - (int64_t)C.q : s;
-  return (uint32_t)s;
+// ---- 32-bit arithmetic mod q (q may exceed 2^31, so sums can wrap 32 bits; handled by comparing first)
+RZK_HD uint32_t addq(uint32_t a, uint32_t b, uint32_t q) {   // a, b in [0,q)
+  const uint32_t nb = q - b;
+  const uint32_t d = a - nb;
+  return a < nb ? d + q : d;
+}
+RZK_HD uint32_t subq(uint32_t a, uint32_t b, uint32_t q) {   // a, b in [0,q)
+  const uint32_t d = a - b;
+  return a < b ? d + q : d;
+}
+// a*c*2^{-32} mod q in [0,q);  a, c < 2^32
+RZK_HD uint32_t montq_u(uint32_t a, uint32_t c, const CrtConsts& C) {
+  const uint64_t t = (uint64_t)a * c;
+  const uint32_t m = (uint32_t)t * C.qinv;
+  const uint32_t h = (uint32_t)(((uint64_t)m * C.q) >> 32);
+  const uint32_t hi = (uint32_t)(t >> 32);
+  const uint32_t d = hi - h;
+  return hi < h ? d + C.q : d;
+}
+// centred coefficient (|a| <= (q-1)/2) -> [0,q)
+RZK_HD uint32_t zq_from_centered(int32_t a, uint32_t q) { return (uint32_t)a + (a < 0 ? q : 0u); }
+// [0,q) -> centred representative as int64
+RZK_HD int64_t center_from_zq(uint32_t u, const CrtConsts& C) {
+  const uint32_t lo = u > C.qhalf ? u - C.q : u;   // |.| <= (q-1)/2 < 2^31: the 32-bit pattern is the int32 value
+  return (int64_t)(int32_t)lo;
 }
 // second digit d1 = (X' mod p1 - d0) * p0^{-1} mod p1 from the prime-1 residue r and d0
 RZK_HD uint32_t crt_digit1(uint32_t r, uint32_t d0, int np, const PrimeConsts* pc, const CrtConsts& C) {
@@ -402,7 +423,7 @@ RZK_HD uint32_t crt_digit1(uint32_t r, uint32_t d0, int np, const PrimeConsts* p
 }
 // (d0 + d1 p0) mod q in [0,q)
 RZK_HD uint32_t crt_value01_modq(uint32_t d0, uint32_t d1, const CrtConsts& C) {
-  return to_zq((int64_t)d0 + montq(d1, C.c1, C), C);
+  return addq(d0, montq_u(d1, C.c1, C), C.q);   // d0 < p0 < q
 }
 // (d0 + d1 p0) mod p2, lazy [0,2p2) — only needed when a third prime follows
 RZK_HD uint32_t crt_value01_modp2(uint32_t d0, uint32_t d1, const PrimeConsts* pc, const CrtConsts& C) {
@@ -420,11 +441,13 @@ RZK_HD void crt_fold2(uint32_t r, const PrimeConsts* pc, const CrtConsts& C, uin
   const uint32_t a2 = csub(csub(r + C.hmod[3][2], pc[2].twop), pc[2].p);
   const uint32_t t2 = a2 + pc[2].twop - stB;                                 // (0, 3p2)
   const uint32_t d2 = csub(mont_lazy(t2, C.inv012_r, pc[2].p, pc[2].npinv), pc[2].p);
-  stA = to_zq((int64_t)stA + montq(d2, C.c2, C), C);
+  stA = addq(stA, montq_u(d2, C.c2, C), C.q);
 }
-// X' mod q -> centred representative of X = X' - H_np
+// X' mod q -> X mod q in [0,q)   (X = X' - H_np)
+RZK_HD uint32_t crt_finish_zq(uint32_t stA, int np, const CrtConsts& C) { return subq(stA, C.hmodq[np], C.q); }
+// ... and its centred representative
 RZK_HD int64_t crt_finish(uint32_t stA, int np, const CrtConsts& C) {
-  return center_rounds<1>((int64_t)stA - (int64_t)C.hmodq[np], C);
+  return center_from_zq(crt_finish_zq(stA, np, C), C);
 }
 
 }  // namespace rzk

@@ -86,14 +86,17 @@ __device__ __forceinline__ const int64_t* operand_ptr(const Operands& ops, uint3
 #ifndef RZK_EPI_CHUNK
 #define RZK_EPI_CHUNK 16  // coefficients per lane handled together in the epilogue (4 was slower: fewer loads in flight)
 #endif
-#ifndef RZK_OPAQUE_LANE
-#define RZK_OPAQUE_LANE 0   // 1: recompute lane-dependent addresses per term (fewer VGPRs, more ALU; measured: no gain)
+// Opaque copy of the lane id inside the loops: stops the compiler from hoisting every lane-dependent
+// address out of the loops (where they sit in dozens of VGPRs) at the price of recomputing them per
+// term.  Measured at N = 1024: no gain (123 -> 74 VGPRs but LDS already caps the kernel at 4 waves per
+// SIMD); at N = 2048 it takes the kernel from 254 VGPRs (1 wave per SIMD) to ~125 (4 waves).
+#ifndef RZK_OPAQUE_LANE_MIN_LOGN
+#define RZK_OPAQUE_LANE_MIN_LOGN 11
 #endif
-#if RZK_OPAQUE_LANE
-#define RZK_OPAQUE(v) asm volatile("" : "+v"(v))
-#else
-#define RZK_OPAQUE(v) do { } while (0)
-#endif
+#define RZK_OPAQUE(v)                                              \
+  do {                                                             \
+    if (LOGN >= RZK_OPAQUE_LANE_MIN_LOGN) asm volatile("" : "+v"(v)); \
+  } while (0)
 
 // Load one coefficient polynomial (coalesced phase-1 layout), lift it into prime field `pc` and,
 // on the first prime pass, also return its 1-norm and max-norm (wave-uniform).
@@ -272,37 +275,42 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
       }
     }
 
-    // plain additions, then store / zero test — in chunks of four coefficients per lane so that only a
-    // few 64-bit values are live at a time
+    // plain additions in 32-bit arithmetic mod q, then centre and store / zero test; RZK_EPI_CHUNK
+    // coefficients per lane at a time
     int nz = 0;
     constexpr int CH = RZK_EPI_CHUNK < E ? RZK_EPI_CHUNK : E;
+    const uint32_t q = T.crt.q;
 #pragma unroll
     for (int e0 = 0; e0 < E; e0 += CH) {
-      int64_t s4[CH];
+      uint32_t u[CH];
       if (has_terms) {
 #pragma unroll
-        for (int i = 0; i < CH; ++i) s4[i] = crt_finish(st_lds[G::j_p1(lane, e0 + i)], np, T.crt);
+        for (int i = 0; i < CH; ++i) u[i] = crt_finish_zq(st_lds[G::j_p1(lane, e0 + i)], np, T.crt);
       } else {
 #pragma unroll
-        for (int i = 0; i < CH; ++i) s4[i] = 0;
+        for (int i = 0; i < CH; ++i) u[i] = 0;
       }
 #pragma unroll 1
       for (uint32_t a = 0; a < row.nadds; ++a) {
         const AddTerm ad = prog->adds[row.add0 + a];
-        const int32_t* __restrict__ src =
-            reinterpret_cast<const int32_t*>(operand_ptr(ops, ad.op, ad.off, b, bo, N));
-        const int64_t sg = ad.sign >= 0 ? 1 : -1;
+        const int64_t* __restrict__ src = operand_ptr(ops, ad.op, ad.off, b, bo, N);
+        if (ad.sign >= 0) {
 #pragma unroll
-        for (int i = 0; i < CH; ++i)
-          s4[i] = center_rounds<1>(s4[i] + sg * (int64_t)src[2 * G::j_p1(lane, e0 + i)], T.crt);
+          for (int i = 0; i < CH; ++i)
+            u[i] = addq(u[i], zq_from_centered((int32_t)src[G::j_p1(lane, e0 + i)], q), q);
+        } else {
+#pragma unroll
+          for (int i = 0; i < CH; ++i)
+            u[i] = subq(u[i], zq_from_centered((int32_t)src[G::j_p1(lane, e0 + i)], q), q);
+        }
       }
       if (row.mode == MODE_STORE) {
         int64_t* __restrict__ dst = const_cast<int64_t*>(operand_ptr(ops, row.out_op, row.out_off, b, bo, N));
 #pragma unroll
-        for (int i = 0; i < CH; ++i) dst[G::j_p1(lane, e0 + i)] = s4[i];
+        for (int i = 0; i < CH; ++i) dst[G::j_p1(lane, e0 + i)] = center_from_zq(u[i], T.crt);
       } else {
 #pragma unroll
-        for (int i = 0; i < CH; ++i) nz |= (s4[i] != 0);
+        for (int i = 0; i < CH; ++i) nz |= (u[i] != 0);
       }
     }
     if (row.mode != MODE_STORE) {

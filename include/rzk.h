@@ -48,7 +48,10 @@ typedef struct rzk_ctx rzk_ctx;
 /* ---- context ---------------------------------------------------------------------------------- */
 /* Mirrors Params<ZqI64<Q>> (src/params.rs:18-36) + const generics N and Q.
  * q: ring modulus Q (odd, < 2^32; default 3515337053, src/params.rs:121), NOT Params.q.
- * N: 512, 1024 or 2048.  Requires k > n >= 1, l >= 1, n + l <= k (src/params.rs:26-31).
+ * N: power of two in [4, 2048].  512 / 1024 / 2048 run the NTT kernels (the BASELINE sizes); 4 .. 256
+ * (the sizes of the reference's own tests: src/mat.rs:241 N=4, tests/test.rs:8 N=16) run a schoolbook
+ * kernel, same results, for drop-in completeness.  Requires k > n >= 1, l >= 1, n + l <= k
+ * (src/params.rs:26-31).
  * device: HIP device ordinal. */
 int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k, uint32_t l,
                    uint32_t kappa, uint64_t b, int device);

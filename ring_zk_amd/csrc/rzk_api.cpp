@@ -66,6 +66,9 @@ struct rzk_ctx {
   DevTables* dT = nullptr;
   uint32_t* d_tw = nullptr;
   uint32_t* d_row_scratch = nullptr;   // per-wave Garner state of the row kernel (third prime only)
+  bool small = false;                  // N < 512: schoolbook kernels (rzk_kernels.hip, "small ring degrees")
+  uint32_t r2q = 0;                    // 2^64 mod q
+  uint32_t* d_key_mont = nullptr;      // small N: key entries as Montgomery-form residues mod q
   // key
   bool key_loaded = false;
   std::vector<uint8_t> key_class;     // (n+l)*k
@@ -414,8 +417,10 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
     c->prof_used++;
     HIPCHK(c, hipEventRecord(e0, c->stream));
   }
-  int lrc = launch_row_program((int)c->logn, cfg_of(c), dp.d, dp.nrows, dp.has_vec, ops, c->d_key_ntt,
-                               c->d_key_inf, c->dT, c->d_tw, c->d_row_scratch, flags, batch);
+  int lrc = c->small ? launch_row_program_small(c->N, cfg_of(c), dp.d, dp.nrows, ops, c->d_key_mont, c->dT, c->r2q,
+                                                flags, batch)
+                     : launch_row_program((int)c->logn, cfg_of(c), dp.d, dp.nrows, dp.has_vec, ops, c->d_key_ntt,
+                                          c->d_key_inf, c->dT, c->d_tw, c->d_row_scratch, flags, batch);
   if (lrc == -2) return fail(c, RZK_E_UNSUPPORTED, "batch * rows must stay below 2^32");
   if (lrc != 0) {
     c->err = std::string("row kernel launch: ") + (lrc > 0 ? hipGetErrorString((hipError_t)lrc) : "bad ring degree");
@@ -443,6 +448,7 @@ int run_norm(rzk_ctx* c, const int64_t* v, uint32_t rows, uint64_t bound, uint8_
   if (bound >= (1ull << 32)) return fail(c, RZK_E_ARG, "norm bound must be below 2^32");
   uint64_t hi, lo;
   norm_limit(bound, hi, lo);
+  if (c->small) return check_launch(c, launch_norm_small(c->N, cfg_of(c), v, rows, hi, lo, ok, B, mode, shift), "norm kernel");
   return check_launch(c, launch_norm((int)c->logn, cfg_of(c), v, rows, hi, lo, ok, B, mode, shift), "norm kernel");
 }
 
@@ -488,7 +494,8 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
                    uint64_t b, int device) {
   if (!out) return RZK_E_ARG;
   *out = nullptr;
-  if (N != 512 && N != 1024 && N != 2048) return create_fail(RZK_E_UNSUPPORTED, "ring degree must be 512, 1024 or 2048");
+  const bool pow2 = N >= 4 && (N & (N - 1)) == 0;
+  if (!pow2 || N > 2048) return create_fail(RZK_E_UNSUPPORTED, "ring degree must be a power of two in [4, 2048]");
   if (n < 1 || l < 1 || k <= n || n + l > k)   // params.rs:26-31: k > n >= l ; a2' has k-n-l cols
     return create_fail(RZK_E_ARG, "need k > n >= 1, l >= 1, n + l <= k");
   if (q < 3) return create_fail(RZK_E_ARG, "bad modulus");
@@ -500,7 +507,10 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
   c->device = device;
   c->q = q;
   c->N = N;
-  c->logn = N == 512 ? 9 : (N == 1024 ? 10 : 11);
+  c->logn = 0;
+  while ((1u << c->logn) < N) ++c->logn;
+  c->small = N < 512;
+  c->r2q = (uint32_t)((((unsigned __int128)1) << 64) % (unsigned __int128)q);
   c->n = n;
   c->k = k;
   c->l = l;
@@ -539,8 +549,8 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
              hipMemcpy(c->d_tw, all.data(), all.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
   c->hT.cap[0] = 0.0;
   for (int np = 1; np <= kMaxPrimes; ++np) c->hT.cap[np] = host::crt_capacity(np);
-  okk = okk && hipMalloc((void**)&c->d_row_scratch, row_scratch_words((int)c->logn, c->num_cus) * sizeof(uint32_t)) ==
-                   hipSuccess;
+  okk = okk && (c->small || hipMalloc((void**)&c->d_row_scratch,
+                                      row_scratch_words((int)c->logn, c->num_cus) * sizeof(uint32_t)) == hipSuccess);
   okk = okk && hipMalloc((void**)&c->dT, sizeof(DevTables)) == hipSuccess &&
         hipMemcpy(c->dT, &c->hT, sizeof(DevTables), hipMemcpyHostToDevice) == hipSuccess;
   if (!okk) {
@@ -567,6 +577,7 @@ void rzk_ctx_destroy(rzk_ctx* c) {
   if (c->dT) (void)hipFree(c->dT);
   if (c->d_tw) (void)hipFree(c->d_tw);
   if (c->d_row_scratch) (void)hipFree(c->d_row_scratch);
+  if (c->d_key_mont) (void)hipFree(c->d_key_mont);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -632,9 +643,22 @@ static int key_load_impl(rzk_ctx* c, const int64_t* a_host) {
   drop_programs(c);   // programs depend on the classification
   if (c->d_key_ntt) HIPCHK(c, hipFree(c->d_key_ntt));
   if (c->d_key_inf) HIPCHK(c, hipFree(c->d_key_inf));
+  if (c->d_key_mont) HIPCHK(c, hipFree(c->d_key_mont));
   c->d_key_ntt = nullptr;
   c->d_key_inf = nullptr;
-  if (c->n_general) {
+  c->d_key_mont = nullptr;
+  if (c->n_general && c->small) {
+    const size_t gbytes = general.size() * sizeof(int64_t);
+    int rc = arena_reserve(c, c->stage, gbytes);
+    if (rc != RZK_OK) return rc;
+    HIPCHK(c, hipMalloc((void**)&c->d_key_mont, general.size() * sizeof(uint32_t)));
+    HIPCHK(c, hipMemcpyAsync(c->stage.p, general.data(), gbytes, hipMemcpyHostToDevice, c->stream));
+    rc = check_launch(c, launch_key_mont(cfg_of(c), (const int64_t*)c->stage.p, c->d_key_mont, general.size(), c->dT,
+                                         c->r2q),
+                      "key conversion");
+    if (rc != RZK_OK) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  } else if (c->n_general) {
     const size_t gbytes = general.size() * sizeof(int64_t);
     int rc = arena_reserve(c, c->stage, gbytes);
     if (rc != RZK_OK) return rc;
@@ -710,16 +734,19 @@ int rzk_norm2_le_batch_dev(rzk_ctx* c, const int64_t* v, uint32_t rows, uint64_t
 
 int rzk_eq_batch_dev(rzk_ctx* c, const int64_t* a, const int64_t* b, uint32_t rows, uint8_t* eq, size_t B) {
   if (!c || !a || !b || !eq || rows == 0) return RZK_E_ARG;
+  if (c->small) return check_launch(c, launch_eq_small(c->N, cfg_of(c), a, b, rows, eq, B), "eq kernel");
   return check_launch(c, launch_eq((int)c->logn, cfg_of(c), a, b, rows, eq, B), "eq kernel");
 }
 
 int rzk_ntt_forward_batch_dev(rzk_ctx* c, int prime, const uint32_t* in, uint32_t* out, size_t count) {
   if (!c || !in || !out || prime < 0 || prime >= kMaxPrimes) return RZK_E_ARG;
+  if (c->small) return fail(c, RZK_E_UNSUPPORTED, "batched transforms need N >= 512");
   return check_launch(c, launch_ntt((int)c->logn, false, cfg_of(c), prime, in, out, count, c->dT, c->d_tw), "ntt forward");
 }
 
 int rzk_ntt_inverse_batch_dev(rzk_ctx* c, int prime, const uint32_t* in, uint32_t* out, size_t count) {
   if (!c || !in || !out || prime < 0 || prime >= kMaxPrimes) return RZK_E_ARG;
+  if (c->small) return fail(c, RZK_E_UNSUPPORTED, "batched transforms need N >= 512");
   return check_launch(c, launch_ntt((int)c->logn, true, cfg_of(c), prime, in, out, count, c->dT, c->d_tw), "ntt inverse");
 }
 
@@ -729,7 +756,7 @@ uint32_t rzk_ntt_psi(int prime, uint32_t N) {
   return host::psi_for(prime, N);
 }
 uint32_t rzk_ntt_layout_index(uint32_t N, uint32_t j) {
-  if (j >= N) return 0xffffffffu;
+  if (j >= N || N < 512) return 0xffffffffu;
   const uint32_t E = N / 64;
   const uint32_t lane = j / E, c = j % E;
   return (c >> 2) * 256 + lane * 4 + (c & 3);

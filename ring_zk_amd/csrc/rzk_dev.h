@@ -94,6 +94,16 @@ int launch_norm(int logn, const LaunchCfg& cfg, const int64_t* v, uint32_t rows,
                 uint64_t limit_lo, uint8_t* ok, uint64_t B, int and_mode, int shift);
 int launch_eq(int logn, const LaunchCfg& cfg, const int64_t* a, const int64_t* b, uint32_t rows,
               uint8_t* eq, uint64_t B);
+// small ring degrees (N = 4 .. 256): schoolbook products mod q, same row programs
+int launch_row_program_small(uint32_t N, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows,
+                             const Operands& ops, const uint32_t* d_key_mont, const DevTables* d_T, uint32_t r2q,
+                             uint8_t* d_flags, uint64_t batch);
+int launch_key_mont(const LaunchCfg& cfg, const int64_t* d_key, uint32_t* d_key_mont, uint64_t ncoef,
+                    const DevTables* d_T, uint32_t r2q);
+int launch_norm_small(uint32_t N, const LaunchCfg& cfg, const int64_t* v, uint32_t rows, uint64_t limit_hi,
+                      uint64_t limit_lo, uint8_t* ok, uint64_t B, int and_mode, int shift);
+int launch_eq_small(uint32_t N, const LaunchCfg& cfg, const int64_t* a, const int64_t* b, uint32_t rows,
+                    uint8_t* eq, uint64_t B);
 int launch_fill_u8(const LaunchCfg& cfg, uint8_t* p, uint8_t v, uint64_t n);
 
 }  // namespace rzk

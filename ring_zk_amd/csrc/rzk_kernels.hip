@@ -525,6 +525,154 @@ __global__ void __launch_bounds__(256) fill_u8_kernel(uint8_t* p, uint8_t v, uin
 }
 
 // =============================================================================================
+// Small ring degrees (N = 4 .. 256): the reference's own unit / integration tests run at N = 4 and
+// N = 16 (src/mat.rs:241, tests/test.rs:8).  One wavefront still owns one row task, but a transform
+// makes no sense below one coefficient per lane, so products are the O(N^2) negacyclic convolution
+// in 32-bit Montgomery arithmetic mod q, operands staged in LDS.  Same row programs, operand tables,
+// epilogue and flags as the big-N kernel; this path exists for drop-in completeness, not for speed.
+// =============================================================================================
+__global__ void __launch_bounds__(256)
+row_kernel_small(const Program* __restrict__ prog, const Operands ops, const uint32_t* __restrict__ key_mont,
+                 const DevTables* __restrict__ Tp, uint8_t* __restrict__ flags, const uint32_t ntasks,
+                 const uint32_t N, const uint32_t r2q) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t* la = smem + wave * 2 * N;   // left operand, plain residues in [0,q)
+  uint32_t* lb = la + N;                // right operand, Montgomery form
+  const DevTables& T = *Tp;
+  const uint32_t q = T.crt.q;
+  const uint32_t nrows = prog->nrows;
+  constexpr int EMAX = 4;               // N <= 256 -> at most 4 coefficients per lane
+
+  for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
+    const uint32_t b = task / nrows;
+    const uint32_t rowi = task - b * nrows;
+    const uint32_t bo = ops.group > 1 ? b / ops.group : b;
+    const Row row = prog->rows[rowi];
+    uint64_t pos[EMAX], neg[EMAX];
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) pos[e] = neg[e] = 0;
+
+    for (uint32_t t = 0; t < row.nterms; ++t) {
+      const Term tm = prog->terms[row.term0 + t];
+      const int64_t* __restrict__ pb = operand_ptr(ops, tm.b_op, tm.b_off, b, bo, (int)N);
+      if (tm.kind == TERM_KEY) {
+        const uint32_t* __restrict__ km = key_mont + (size_t)tm.a_off * N;
+        for (uint32_t i = lane; i < N; i += 64) {
+          la[i] = zq_from_centered((int32_t)pb[i], q);
+          lb[i] = km[i];
+        }
+      } else {
+        const int64_t* __restrict__ pa = operand_ptr(ops, tm.a_op, tm.a_off, b, bo, (int)N);
+        for (uint32_t i = lane; i < N; i += 64) {
+          la[i] = zq_from_centered((int32_t)pa[i], q);
+          lb[i] = montq_u(zq_from_centered((int32_t)pb[i], q), r2q, T.crt);
+        }
+      }
+      wave_sync();
+#pragma unroll
+      for (int e = 0; e < EMAX; ++e) {
+        const uint32_t tt = lane + 64 * e;
+        if (tt < N) {
+          uint64_t p = 0, m = 0;
+          for (uint32_t i = 0; i < N; ++i) {
+            const uint32_t prod = montq_u(la[i], lb[(tt - i) & (N - 1)], T.crt);
+            if (i > tt) m += prod; else p += prod;   // X^N = -1
+          }
+          if (tm.sign >= 0) { pos[e] += p; neg[e] += m; } else { pos[e] += m; neg[e] += p; }
+        }
+      }
+      wave_sync();
+    }
+
+    int nz = 0;
+#pragma unroll
+    for (int e = 0; e < EMAX; ++e) {
+      const uint32_t tt = lane + 64 * e;
+      if (tt < N) {
+        uint32_t u = subq((uint32_t)(pos[e] % q), (uint32_t)(neg[e] % q), q);
+        for (uint32_t a = 0; a < row.nadds; ++a) {
+          const AddTerm ad = prog->adds[row.add0 + a];
+          const uint32_t v = zq_from_centered((int32_t)operand_ptr(ops, ad.op, ad.off, b, bo, (int)N)[tt], q);
+          u = ad.sign >= 0 ? addq(u, v, q) : subq(u, v, q);
+        }
+        if (row.mode == MODE_STORE)
+          const_cast<int64_t*>(operand_ptr(ops, row.out_op, row.out_off, b, bo, (int)N))[tt] = center_from_zq(u, T.crt);
+        else
+          nz |= (u != 0);
+      }
+    }
+    if (row.mode != MODE_STORE) {
+      if (__any(nz) && lane == 0) flags[bo] = 0;
+    }
+  }
+}
+
+// key entries -> Montgomery-form residues mod q (one thread per coefficient)
+__global__ void __launch_bounds__(256)
+key_mont_kernel(const int64_t* __restrict__ key, uint32_t* __restrict__ key_mont, uint64_t ncoef,
+                const DevTables* __restrict__ Tp, uint32_t r2q) {
+  const DevTables& T = *Tp;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncoef; i += (uint64_t)gridDim.x * blockDim.x)
+    key_mont[i] = montq_u(zq_from_centered((int32_t)key[i], T.crt.q), r2q, T.crt);
+}
+
+// norm / equality for any N (used below N = 512): one wavefront per proof
+__global__ void __launch_bounds__(256)
+norm_kernel_small(const int64_t* __restrict__ v, uint32_t rows, uint64_t limit_hi, uint64_t limit_lo,
+                  uint8_t* __restrict__ ok, uint64_t B, int and_mode, int shift, uint32_t N) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (uint64_t b = (uint64_t)blockIdx.x * 4 + wave; b < B; b += (uint64_t)gridDim.x * 4) {
+    int good = 1;
+    for (uint32_t r = 0; r < rows; ++r) {
+      const int64_t* __restrict__ p = v + (b * rows + r) * N;
+      uint64_t slo = 0, shi = 0;
+      int huge = 0;
+      for (uint32_t i = lane; i < N; i += 64) {
+        const int64_t c = p[i];
+        const uint64_t a = c < 0 ? 0ull - (uint64_t)c : (uint64_t)c;
+        huge |= (a >> 32) != 0;
+        const uint64_t al = a & 0xffffffffu;
+        const uint64_t ll = al * al;
+        slo += ll & 0xffffffffu;
+        shi += ll >> 32;
+      }
+      slo = wave_sum_u64(slo);
+      shi = wave_sum_u64(shi);
+      const uint64_t mid = shi + (slo >> 32);
+      const uint64_t tot_lo = (mid << 32) | (slo & 0xffffffffu);
+      const uint64_t tot_hi = mid >> 32;
+      const int lt = (tot_hi < limit_hi) || (tot_hi == limit_hi && tot_lo < limit_lo);
+      good &= lt && !__any(huge);
+    }
+    if (lane == 0) {
+      if (and_mode == 0)
+        ok[b] = (uint8_t)good;
+      else if (and_mode == 1)
+        ok[b] = (uint8_t)(ok[b] & good);
+      else
+        ok[b] = (uint8_t)(ok[b] | (good << shift));
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+eq_kernel_small(const int64_t* __restrict__ a, const int64_t* __restrict__ b, uint32_t rows,
+                uint8_t* __restrict__ eq, uint64_t B, uint32_t N) {
+  const uint32_t lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (uint64_t p = (uint64_t)blockIdx.x * 4 + wave; p < B; p += (uint64_t)gridDim.x * 4) {
+    int ne = 0;
+    const uint64_t n = (uint64_t)rows * N;
+    for (uint64_t i = lane; i < n; i += 64) ne |= (a[p * n + i] != b[p * n + i]);
+    const int any_ne = __any(ne);
+    if (lane == 0) eq[p] = (uint8_t)(any_ne ? 0 : 1);
+  }
+}
+
+// =============================================================================================
 // Launchers
 // =============================================================================================
 static inline unsigned grid_for(uint64_t tasks, int num_cus, int waves_per_block = 4, int blocks_per_cu = 8) {
@@ -687,6 +835,49 @@ int launch_fill_u8(const LaunchCfg& cfg, uint8_t* p, uint8_t v, uint64_t n) {
   uint64_t blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(fill_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)cfg.stream, p, v, n);
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- small ring degrees ------------------------------------------------------------------------------------------
+int launch_row_program_small(uint32_t N, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows,
+                             const Operands& ops, const uint32_t* d_key_mont, const DevTables* T, uint32_t r2q,
+                             uint8_t* d_flags, uint64_t batch) {
+  if (batch == 0 || nrows == 0) return 0;
+  if (batch * nrows >= (1ull << 32)) return -2;
+  const uint32_t ntasks = (uint32_t)(batch * nrows);
+  const unsigned grid = grid_for(ntasks, cfg.num_cus);
+  hipLaunchKernelGGL(row_kernel_small, dim3(grid), dim3(256), 4 * 2 * N * sizeof(uint32_t), (hipStream_t)cfg.stream,
+                     d_prog, ops, d_key_mont, T, d_flags, ntasks, N, r2q);
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_key_mont(const LaunchCfg& cfg, const int64_t* d_key, uint32_t* d_key_mont, uint64_t ncoef,
+                    const DevTables* T, uint32_t r2q) {
+  if (ncoef == 0) return 0;
+  uint64_t blocks = (ncoef + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(key_mont_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)cfg.stream, d_key,
+                     d_key_mont, ncoef, T, r2q);
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_norm_small(uint32_t N, const LaunchCfg& cfg, const int64_t* v, uint32_t rows, uint64_t limit_hi,
+                      uint64_t limit_lo, uint8_t* ok, uint64_t B, int and_mode, int shift) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(norm_kernel_small, dim3(grid_for(B, cfg.num_cus)), dim3(256), 0, (hipStream_t)cfg.stream, v,
+                     rows, limit_hi, limit_lo, ok, B, and_mode, shift, N);
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_eq_small(uint32_t N, const LaunchCfg& cfg, const int64_t* a, const int64_t* b, uint32_t rows,
+                    uint8_t* eq, uint64_t B) {
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(eq_kernel_small, dim3(grid_for(B, cfg.num_cus)), dim3(256), 0, (hipStream_t)cfg.stream, a, b,
+                     rows, eq, B, N);
   RZK_LAUNCH_CHECK();
   return 0;
 }

@@ -36,6 +36,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--N", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=4096, help="proofs per GPU and step")
+    ap.add_argument("--workload", choices=["open", "linear", "sum"], default="open",
+                    help="open = BASELINE metric config; linear / sum = the other BASELINE configs")
+    ap.add_argument("--shape", type=str, default="1,3,1", help="n,k,l")
+    ap.add_argument("--summands", type=int, default=8, help="V for --workload sum")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target length of the CPU baseline sample")
     return ap.parse_args()
@@ -102,7 +106,9 @@ def main():
 
     from ring_zk_amd import Context, shard, synth
 
-    N, n, k, l = args.N, 1, 3, 1
+    N = args.N
+    n, k, l = (int(v) for v in args.shape.split(","))
+    V = args.summands
     B = args.batch
     dev = torch.device("cuda", local_rank)
     ctx = Context(N, n, k, l, device=local_rank)
@@ -115,17 +121,62 @@ def main():
     ctx.load_key(A)
     g = torch.Generator(device=dev)
     g.manual_seed(1000 + rank)
-    x = synth.t_uniform(g, (B, l, N), dev)
-    r = synth.t_small(g, (B, k, N), dev)
-    y = synth.t_gauss(g, (B, k, N), dev, sig)
     d = synth.t_challenge(g, B, N, ctx.kappa, dev)
+    if args.workload == "open":
+        x = synth.t_uniform(g, (B, l, N), dev)
+        r = synth.t_small(g, (B, k, N), dev)
+        y = synth.t_gauss(g, (B, k, N), dev, sig)
+        cycle_polys = (l + 2 * k) + (2 * n + l) + (2 * k + 1) + k + (k + 2 * n + 1)   # 26 at (1,3,1): SURVEY §8d
+        row_launches = 3
+
+        def phases():
+            c, t, ok = ctx.open_commit(x, r, y)
+            yield "commit"
+            z = ctx.open_response(y, r, d)
+            yield "response"
+            acc = ctx.open_verify(z, t, c, d)
+            yield "verify"
+            phases.result = (ok, acc)
+    elif args.workload == "linear":
+        gp = synth.t_uniform(g, (B, N), dev)
+        x = synth.t_uniform(g, (B, l, N), dev)
+        r, rp = synth.t_small(g, (B, k, N), dev), synth.t_small(g, (B, k, N), dev)
+        y, yp = synth.t_gauss(g, (B, k, N), dev, sig), synth.t_gauss(g, (B, k, N), dev, sig)
+        cycle_polys = ((1 + l + 4 * k) + (4 * n + 3 * l)) + ((4 * k + 1) + 2 * k) + (2 * k + 2 * (n + l) + 1 + 2 * n + l + 1)
+        row_launches = 3 + 1 + 2
+
+        def phases():
+            c, cp, t, tp, u, ok = ctx.linear_commit(gp, x, r, rp, y, yp)
+            yield "commit"
+            z, zp = ctx.linear_response(y, yp, r, rp, d)
+            yield "response"
+            acc = ctx.linear_verify(z, zp, c, cp, gp, t, tp, u, d)
+            yield "verify"
+            phases.result = ((ok == 3).to(torch.uint8), acc)
+    else:
+        gs = synth.t_uniform(g, (B, V, N), dev)
+        xs = synth.t_uniform(g, (B, V, l, N), dev)
+        rs, rp = synth.t_small(g, (B, V, k, N), dev), synth.t_small(g, (B, k, N), dev)
+        ys, yp = synth.t_gauss(g, (B, V, k, N), dev, sig), synth.t_gauss(g, (B, k, N), dev, sig)
+        cycle_polys = ((V + V * l + 2 * V * k + 2 * k) + ((V + 1) * (n + l) + (V + 1) * n + l)) + \
+                      ((2 * V * k + 2 * k + 1) + (V + 1) * k) + \
+                      ((V + 1) * k + (V + 1) * (n + l) + V + (V + 1) * n + l + 1)
+        row_launches = 5 + 2 + 5
+
+        def phases():
+            cs, cp, ts, tp, u, ok = ctx.sum_commit(gs, xs, rs, rp, ys, yp)
+            yield "commit"
+            zs, zp = ctx.sum_response(ys, yp, rs, rp, d)
+            yield "response"
+            acc = ctx.sum_verify(zs, zp, cs, cp, gs, ts, tp, u, d)
+            yield "verify"
+            phases.result = (ok, acc)
     torch.cuda.synchronize()
 
     def step():
-        c, t, ok = ctx.open_commit(x, r, y)
-        z = ctx.open_response(y, r, d)
-        acc = ctx.open_verify(z, t, c, d)
-        return ok, acc
+        for _ in phases():
+            pass
+        return phases.result
 
     def barrier():
         shard.barrier(dist, dev)
@@ -163,19 +214,15 @@ def main():
         evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(psteps)]
         for i in range(psteps):
             evs[i][0].record()
-            c_, t_, _ok = ctx.open_commit(x, r, y)
-            evs[i][1].record()
-            z_ = ctx.open_response(y, r, d)
-            evs[i][2].record()
-            ctx.open_verify(z_, t_, c_, d)
-            evs[i][3].record()
+            for j, _name in enumerate(phases()):
+                evs[i][j + 1].record()
         torch.cuda.synchronize()
         phase_us = {name: sum(evs[i][j].elapsed_time(evs[i][j + 1]) for i in range(psteps)) / psteps * 1e3
                     for j, name in enumerate(("commit", "response", "verify"))}
-        # algorithmic bytes of one OpenProof cycle at the boundary, key resident:
-        # commit 7 in + 3 out, response 7 in + 3 out, verify 6 in = 26 polynomials of 8*N bytes
-        cycle_bytes = 26 * 8 * N * B
-        per_launch = cycle_bytes / 3.0          # three row-kernel launches per cycle
+        # algorithmic bytes of one cycle at the boundary, key resident: every polynomial a
+        # phase takes in or hands out, 8*N bytes each (Open at (1,3,1): 7+3, 7+3, 6 = 26 polynomials)
+        cycle_bytes = cycle_polys * 8 * N * B
+        per_launch = cycle_bytes / float(row_launches)
         achieved = per_launch / (avg_us * 1e-6) / 1e9
         traffic = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_row_kernel.json")
@@ -185,7 +232,7 @@ def main():
             except Exception:
                 traffic = None
         roofline = {
-            "kernel": "row_kernel<10> (open commit / response / verify row programs)",
+            "kernel": f"row_kernel<log2 N={N.bit_length() - 1}> ({args.workload} commit / response / verify row programs)",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
@@ -208,7 +255,7 @@ def main():
                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ntt_gbs / HBM_PEAK_GBS}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "open":
         cpu = cpu_baseline(N, n, k, l, args.cpu_seconds)
 
     if rank == 0:
@@ -226,7 +273,8 @@ def main():
             "dtype": "u32 residues of three 30-bit primes (int64 coefficients at the boundary)",
             "data": "synthetic",
             "config": {
-                "workload": f"OpenProof cycle, N={N}, (n,k,l)=({n},{k},{l}), kappa=36, batch={B} proofs per GPU",
+                "workload": f"{args.workload.capitalize()}Proof cycle, N={N}, (n,k,l)=({n},{k},{l}), kappa=36, "
+                            + (f"V={V} summands, " if args.workload == "sum" else "") + f"batch={B} proofs per GPU",
                 "challenge": "pre-sampled (host RNG is outside the path)",
                 "parallelism": f"batch split over {world} GPU(s), no data-path collective",
                 "accepted": tot_acc,

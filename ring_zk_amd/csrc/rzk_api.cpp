@@ -184,6 +184,34 @@ struct PB {
   }
 };
 
+// Fused norm predicate: mark, for each polynomial (vop, 0..count-1), the first load in program order
+// (b operand of a product term, or one of the first four additions of a row).  Returns false when some
+// polynomial is never loaded by the program — the caller then keeps the separate norm kernel.
+bool mark_checks(PB& pb, uint8_t vop, uint32_t count) {
+  for (uint32_t j = 0; j < count; ++j) {
+    bool done = false;
+    for (uint32_t r = 0; r < pb.p.nrows && !done; ++r) {
+      const Row& row = pb.p.rows[r];
+      for (uint32_t t = 0; t < row.nterms && !done; ++t) {
+        Term& tm = pb.p.terms[row.term0 + t];
+        if (tm.b_op == vop && tm.b_off == j && !(tm.kind & TERM_CHECK)) {
+          tm.kind |= TERM_CHECK;
+          done = true;
+        }
+      }
+      for (uint32_t a = 0; a < row.nadds && a < 4 && !done; ++a) {
+        AddTerm& ad = pb.p.adds[row.add0 + a];
+        if ((ad.op & ADD_OP_MASK) == vop && ad.off == j && !(ad.op & ADD_CHECK)) {
+          ad.op |= ADD_CHECK;
+          done = true;
+        }
+      }
+    }
+    if (!done) return false;
+  }
+  return true;
+}
+
 // sign * (row `krow` of [a1;a2]) . v, v = operand (vop, voff .. voff+k-1): skips zero entries, turns
 // entries equal to 1 into plain additions (the identity blocks of commit.rs:38-57), products otherwise.
 void key_row(rzk_ctx* c, PB& pb, int sign, uint32_t krow, uint8_t vop, uint32_t voff) {
@@ -232,6 +260,9 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
         pb.begin_row(4, i, MODE_STORE);
         key_row(c, pb, +1, i, 2, 0);
       }
+      if (var & 1) {   // fused check_commit_constraint(r)  (commit.rs:98-107)
+        if (!mark_checks(pb, 1, k)) return RZK_E_UNSUPPORTED;
+      }
       break;
     case PG_RESPONSE:   // ops: 0 = d, then per triple s: 1+3s = y[k], 2+3s = r[k], 3+3s = z[k]
       for (uint32_t s = 0; s < var; ++s)
@@ -249,6 +280,9 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
         key_row(c, pb, +1, i, 0, 0);
         pb.vec_term(-1, 3, 0, 2, i);
         pb.add(-1, 1, i);
+      }
+      if (var & 1) {   // fused check_verify_constraint(z)  (open.rs:167-169)
+        if (!mark_checks(pb, 0, k)) return RZK_E_UNSUPPORTED;
       }
       break;
     case PG_LIN_COMMIT2:
@@ -308,6 +342,9 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
         pb.vec_term(+1, 4, l + i, 7, 0);
         pb.add(-1, 5, l + i);
       }
+      if (var & 1) {   // fused check_verify_constraint(z), (zp)  (linear.rs:218-223)
+        if (!mark_checks(pb, 0, k) || !mark_checks(pb, 1, k)) return RZK_E_UNSUPPORTED;
+      }
       break;
     case PG_LIN_V2:
       // ops: 0 = w1[l], 1 = w2[l], 2 = g, 3 = d, 4 = zp[k], 5 = u[l]
@@ -365,6 +402,7 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
   }
   PB pb;
   int rc = build_program(c, id, var, pb);
+  if (rc == RZK_E_UNSUPPORTED) return rc;   // a fused-check variant that cannot cover every polynomial
   if (rc != RZK_OK) return fail(c, rc, "unknown program");
   if (pb.overflow) return fail(c, RZK_E_UNSUPPORTED, "shape exceeds row-program capacity");
   DevProg dp;
@@ -372,7 +410,7 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
   HIPCHK(c, hipMemcpyAsync(dp.d, &pb.p, sizeof(Program), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));   // pb.p is a stack object; one-off per (program, shape)
   dp.nrows = pb.p.nrows;
-  for (uint32_t t = 0; t < pb.p.nterms; ++t) dp.has_vec = dp.has_vec || pb.p.terms[t].kind == TERM_VEC;
+  for (uint32_t t = 0; t < pb.p.nterms; ++t) dp.has_vec = dp.has_vec || (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_VEC;
   c->progs[{id, var}] = dp;
   out = dp;
   return RZK_OK;
@@ -392,7 +430,7 @@ struct OpSpec {
 
 // `group` > 1: the batch is B*group (proof, summand) pairs; operands with outer != 0 and the flags are per proof
 int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& specs, uint8_t* flags,
-                uint32_t group, uint64_t batch) {
+                uint32_t group, uint64_t batch, uint64_t norm_limit = 0) {
   DevProg dp;
   int rc = get_program(c, id, var, dp);
   if (rc != RZK_OK) return rc;
@@ -404,6 +442,7 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
     ops.outer[i] = specs[i].outer ? 1 : 0;
   }
   ops.group = group ? group : 1;
+  ops.norm_limit = norm_limit;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->prof) {
     if (c->prof_used == c->prof_events.size()) {
@@ -441,6 +480,30 @@ void norm_limit(uint64_t bound, uint64_t& hi, uint64_t& lo) {
   unsigned __int128 v = (unsigned __int128)(bound + 1) * (bound + 1);
   hi = (uint64_t)(v >> 64);
   lo = (uint64_t)v;
+}
+
+// (bound+1)^2 when the fused predicate applies (NTT kernels only, limit <= 2^48), else 0
+uint64_t fused_limit(const rzk_ctx* c, uint64_t bound) {
+  if (c->small || bound >= (1ull << 24) - 1) return 0;
+  return (bound + 1) * (bound + 1);
+}
+
+// Runs the checked variant (var | 1) of a program with the norm predicate fused into it: flags are
+// preset to 1 and cleared by failing rows.  Returns RZK_E_UNSUPPORTED when fusion is not possible.
+int run_program_checked(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& specs, uint8_t* flags,
+                        uint32_t group, uint64_t batch, uint64_t nflags, uint64_t bound, bool preset = true) {
+  const uint64_t lim = fused_limit(c, bound);
+  if (!lim || !flags) return RZK_E_UNSUPPORTED;
+  DevProg dp;
+  int rc = get_program(c, id, var | 1, dp);
+  if (rc != RZK_OK) return rc;
+  if (preset) HIPCHK(c, hipMemsetAsync(flags, 1, nflags, c->stream));
+  return run_program(c, id, var | 1, specs, flags, group, batch, lim);
+}
+
+bool can_fuse(rzk_ctx* c, int id, uint32_t var, uint64_t bound) {
+  DevProg dp;
+  return fused_limit(c, bound) != 0 && get_program(c, id, var | 1, dp) == RZK_OK;
 }
 
 int run_norm(rzk_ctx* c, const int64_t* v, uint32_t rows, uint64_t bound, uint8_t* ok, uint64_t B, int mode,
@@ -768,10 +831,13 @@ uint32_t rzk_ntt_layout_index(uint32_t N, uint32_t j) {
 int rzk_open_commit_batch_dev(rzk_ctx* c, const int64_t* x, const int64_t* r, const int64_t* y, int64_t* cm,
                               int64_t* t, uint8_t* ok, size_t B) {
   if (!c || !x || !r || !y || !cm || !t) return RZK_E_ARG;
-  int rc = run_program(c, PG_OPEN_COMMIT, 0,
-                       {{x, c->l, 0}, {r, c->k, 0}, {y, c->k, 0}, {cm, c->n + c->l, 0}, {t, c->n, 0}}, nullptr, 1, B);
+  const std::vector<OpSpec> specs = {{x, c->l, 0}, {r, c->k, 0}, {y, c->k, 0}, {cm, c->n + c->l, 0}, {t, c->n, 0}};
+  // check_commit_constraint(r) (params.rs:102-108) rides on the loads of r the commit rows do anyway
+  int rc = run_program_checked(c, PG_OPEN_COMMIT, 0, specs, ok, 1, B, B, c->commit_bound);
+  if (rc != RZK_E_UNSUPPORTED) return rc;
+  rc = run_program(c, PG_OPEN_COMMIT, 0, specs, nullptr, 1, B);
   if (rc != RZK_OK) return rc;
-  if (ok) rc = run_norm(c, r, c->k, c->commit_bound, ok, B, 0, 0);   // params.rs:102-108
+  if (ok) rc = run_norm(c, r, c->k, c->commit_bound, ok, B, 0, 0);
   return rc;
 }
 
@@ -785,9 +851,13 @@ int rzk_open_verify_batch_dev(rzk_ctx* c, const int64_t* z, const int64_t* t, co
                               uint8_t* accept, size_t B) {
   if (!c || !z || !t || !cm || !d || !accept) return RZK_E_ARG;
   if (c->n != c->l) return fail(c, RZK_E_ARG, "c1_c2 split needs n == l (reference panics in Mat::add)");
-  int rc = run_norm(c, z, c->k, c->verify_bound, accept, B, 0, 0);   // open.rs:167-169
+  const std::vector<OpSpec> specs = {{z, c->k, 0}, {t, c->n, 0}, {cm, c->n + c->l, 0}, {d, 1, 0}};
+  // open.rs:167-169: the norm predicate on z is fused into the rows that load z (one launch per verify)
+  int rc = run_program_checked(c, PG_A1_RELATION, 0, specs, accept, 1, B, B, c->verify_bound);
+  if (rc != RZK_E_UNSUPPORTED) return rc;
+  rc = run_norm(c, z, c->k, c->verify_bound, accept, B, 0, 0);
   if (rc != RZK_OK) return rc;
-  return run_program(c, PG_A1_RELATION, 0, {{z, c->k, 0}, {t, c->n, 0}, {cm, c->n + c->l, 0}, {d, 1, 0}}, accept, 1, B);
+  return run_program(c, PG_A1_RELATION, 0, specs, accept, 1, B);
 }
 
 // =================================================================================================
@@ -838,14 +908,17 @@ int rzk_linear_verify_batch_dev(rzk_ctx* c, const int64_t* z, const int64_t* zp,
   if (rc != RZK_OK) return rc;
   int64_t* w1 = (int64_t*)c->ws.p;
   int64_t* w2 = w1 + B * l * c->N;
-  rc = run_norm(c, z, k, c->verify_bound, accept, B, 0, 0);    // linear.rs:218-220
-  if (rc != RZK_OK) return rc;
-  rc = run_norm(c, zp, k, c->verify_bound, accept, B, 1, 0);   // linear.rs:221-223
-  if (rc != RZK_OK) return rc;
-  rc = run_program(c, PG_LIN_V1, 0,
-                   {{z, k, 0}, {zp, k, 0}, {t, n, 0}, {tp, n, 0}, {cm, n + l, 0}, {cpm, n + l, 0}, {d, 1, 0}, {g, 1, 0},
-                    {w1, l, 0}, {w2, l, 0}},
-                   accept, 1, B);
+  const std::vector<OpSpec> v1 = {{z, k, 0}, {zp, k, 0}, {t, n, 0}, {tp, n, 0}, {cm, n + l, 0}, {cpm, n + l, 0},
+                                  {d, 1, 0}, {g, 1, 0}, {w1, l, 0}, {w2, l, 0}};
+  // linear.rs:218-223: norm predicates on z and zp, fused into the rows that load them when possible
+  rc = run_program_checked(c, PG_LIN_V1, 0, v1, accept, 1, B, B, c->verify_bound);
+  if (rc == RZK_E_UNSUPPORTED) {
+    rc = run_norm(c, z, k, c->verify_bound, accept, B, 0, 0);
+    if (rc != RZK_OK) return rc;
+    rc = run_norm(c, zp, k, c->verify_bound, accept, B, 1, 0);
+    if (rc != RZK_OK) return rc;
+    rc = run_program(c, PG_LIN_V1, 0, v1, accept, 1, B);
+  }
   if (rc != RZK_OK) return rc;
   return run_program(c, PG_LIN_V2, 0, {{w1, l, 0}, {w2, l, 0}, {g, 1, 0}, {d, 1, 0}, {zp, k, 0}, {u, l, 0}}, accept, 1, B);
 }
@@ -906,16 +979,25 @@ int rzk_sum_verify_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* zs, const in
   if (rc != RZK_OK) return rc;
   int64_t* w1 = (int64_t*)c->ws.p;
   int64_t* w2 = w1 + B * V * l * c->N;
-  rc = run_norm(c, zs, V * k, c->verify_bound, accept, B, 0, 0);   // sum.rs:262-268
-  if (rc != RZK_OK) return rc;
-  rc = run_norm(c, zp, k, c->verify_bound, accept, B, 1, 0);       // sum.rs:269-271
-  if (rc != RZK_OK) return rc;
-  // sum.rs:278-291: a1.z_i == t_i + c1_i (.) d for every summand (batch entries B*V, flag per proof)
-  rc = run_program(c, PG_A1_RELATION, 0, {{zs, k, 0}, {ts, n, 0}, {cs, n + l, 0}, {d, 1, 1}}, accept, V, B * V);
-  if (rc != RZK_OK) return rc;
-  // sum.rs:294-298
-  rc = run_program(c, PG_A1_RELATION, 0, {{zp, k, 0}, {tp, n, 0}, {cpm, n + l, 0}, {d, 1, 0}}, accept, 1, B);
-  if (rc != RZK_OK) return rc;
+  const std::vector<OpSpec> rel_s = {{zs, k, 0}, {ts, n, 0}, {cs, n + l, 0}, {d, 1, 1}};
+  const std::vector<OpSpec> rel_p = {{zp, k, 0}, {tp, n, 0}, {cpm, n + l, 0}, {d, 1, 0}};
+  if (can_fuse(c, PG_A1_RELATION, 0, c->verify_bound)) {
+    // sum.rs:262-271 norm predicates fused into sum.rs:278-291 (every summand; batch entries B*V, flag per
+    // proof) and sum.rs:294-298
+    rc = run_program_checked(c, PG_A1_RELATION, 0, rel_s, accept, V, B * V, B, c->verify_bound, true);
+    if (rc != RZK_OK) return rc;
+    rc = run_program_checked(c, PG_A1_RELATION, 0, rel_p, accept, 1, B, B, c->verify_bound, false);
+    if (rc != RZK_OK) return rc;
+  } else {
+    rc = run_norm(c, zs, V * k, c->verify_bound, accept, B, 0, 0);   // sum.rs:262-268
+    if (rc != RZK_OK) return rc;
+    rc = run_norm(c, zp, k, c->verify_bound, accept, B, 1, 0);       // sum.rs:269-271
+    if (rc != RZK_OK) return rc;
+    rc = run_program(c, PG_A1_RELATION, 0, rel_s, accept, V, B * V);   // sum.rs:278-291
+    if (rc != RZK_OK) return rc;
+    rc = run_program(c, PG_A1_RELATION, 0, rel_p, accept, 1, B);       // sum.rs:294-298
+    if (rc != RZK_OK) return rc;
+  }
   // sum.rs:301-319
   rc = run_program(c, PG_MATVEC, RZK_KEY_A2 * 2, {{zs, k, 0}, {nullptr, l, 0}, {w1, l, 0}}, nullptr, 1, B * V);
   if (rc != RZK_OK) return rc;

@@ -33,8 +33,15 @@ constexpr int kMaxRows = 48;
 constexpr int kMaxTerms = 640;
 constexpr int kMaxAdds = 128;
 
-enum : uint8_t { TERM_KEY = 0, TERM_VEC = 1 };
+enum : uint8_t { TERM_KEY = 0, TERM_VEC = 1, TERM_KIND_MASK = 0x7f };
 enum : uint8_t { MODE_STORE = 0, MODE_ZERO = 1 };
+// Fused norm predicate (Params::check_*_constraint, src/params.rs:102-118): a term (its b operand) or an
+// addition marked with CHECK also tests sum c^2 < Operands::norm_limit for the polynomial it loads and
+// clears flags[proof] on failure.  The host marks, for each polynomial of the checked vector, the first
+// load in program order, so every polynomial is tested exactly once and no separate norm pass is needed.
+constexpr uint8_t TERM_CHECK = 0x80;   // in Term::kind
+constexpr uint8_t ADD_CHECK = 0x80;    // in AddTerm::op
+constexpr uint8_t ADD_OP_MASK = 0x7f;
 
 struct Term {
   uint8_t kind;     // TERM_KEY: KEY[a_off] (*) operand(b_op, b_off);  TERM_VEC: (a_op,a_off) (*) (b_op,b_off)
@@ -68,6 +75,7 @@ struct Operands {
   uint32_t outer[kMaxOperands];
   uint32_t group;
   uint32_t pad;
+  uint64_t norm_limit;   // (bound+1)^2 of the fused norm predicate; must be <= 2^48 (0 = unused)
 };
 
 // ---- launchers (defined in rzk_kernels.hip) --------------------------------------------------------------------

@@ -100,12 +100,13 @@ __device__ __forceinline__ const int64_t* operand_ptr(const Operands& ops, uint3
 
 // Load one coefficient polynomial (coalesced phase-1 layout), lift it into prime field `pc` and,
 // on the first prime pass, also return its 1-norm and max-norm (wave-uniform).
+// With want_sq it also returns sum min(|c|, 2^24)^2 over the polynomial, which decides sum c^2 < L exactly for
+// every L <= 2^48 (a clamped coefficient alone already reaches 2^48).
 template <int LOGN>
 __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict__ src, int lane,
-                                          const PrimeConsts& pc, bool want_norms, double& l1, double& linf) {
+                                          const PrimeConsts& pc, bool want_norms, double& l1, double& linf,
+                                          bool want_sq, uint64_t& sumsq) {
   using G = Geo<LOGN>;
-  // centred coefficients fit 32 bits: fetch only the low dword of every int64 (same cache lines,
-  // half the registers and half the data returned to the wave)
   int32_t v[G::E];
 #if RZK_LOAD_LO32
   const int32_t* __restrict__ lo = reinterpret_cast<const int32_t*>(src);
@@ -128,6 +129,16 @@ __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict
     }
     l1 = (double)wave_sum_u64(sum);
     linf = (double)wave_max_u32(mx);
+    if (want_sq) {
+      uint64_t sq = 0;
+#pragma unroll
+      for (int e = 0; e < G::E; ++e) {
+        uint32_t a = (uint32_t)(v[e] < 0 ? -v[e] : v[e]);
+        a = a < (1u << 24) ? a : (1u << 24);
+        sq += (uint64_t)a * a;
+      }
+      sumsq = wave_sum_u64(sq);
+    }
   }
 #pragma unroll
   for (int e = 0; e < G::E; ++e) x[e] = lift(v[e], pc);
@@ -191,15 +202,19 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
           RZK_OPAQUE(ln);
           uint32_t x[E];
           double l1b = 0, infb = 0;
-          load_lift<LOGN>(x, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), ln, pc, first, l1b, infb);
+          uint64_t sumsq = 0;
+          const bool chk = first && (tm.kind & TERM_CHECK);
+          load_lift<LOGN>(x, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), ln, pc, first, l1b, infb, chk, sumsq);
+          if (chk && sumsq >= ops.norm_limit && lane == 0) flags[bo] = 0;
           wave_fwd<LOGN>(x, ln, lds, twf, pc);
-          if (HAS_VEC && tm.kind == TERM_VEC) {
+          if (HAS_VEC && (tm.kind & TERM_KIND_MASK) == TERM_VEC) {
             // product of two per-proof polynomials: fold N^-1 and the Montgomery factor into one of them
             uint32_t xb[E];
 #pragma unroll
             for (int c = 0; c < E; ++c) xb[c] = csub(mont_lazy(x[c], pc.ninv_r2, pc.p, pc.npinv), pc.p);
             double l1a = 0, infa = 0;
-            load_lift<LOGN>(x, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), ln, pc, first, l1a, infa);
+            uint64_t unused_sq = 0;
+            load_lift<LOGN>(x, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), ln, pc, first, l1a, infa, false, unused_sq);
             wave_fwd<LOGN>(x, ln, lds, twf, pc);
             if (first) {
               const double u = l1a * infb, v = infa * l1b;
@@ -280,6 +295,7 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
     int nz = 0;
     constexpr int CH = RZK_EPI_CHUNK < E ? RZK_EPI_CHUNK : E;
     const uint32_t q = T.crt.q;
+    uint64_t add_sq[4] = {0, 0, 0, 0};   // per-lane partial sums of squares of checked additions (slot = add index)
 #pragma unroll
     for (int e0 = 0; e0 < E; e0 += CH) {
       uint32_t u[CH];
@@ -293,15 +309,26 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
 #pragma unroll 1
       for (uint32_t a = 0; a < row.nadds; ++a) {
         const AddTerm ad = prog->adds[row.add0 + a];
-        const int64_t* __restrict__ src = operand_ptr(ops, ad.op, ad.off, b, bo, N);
+        const int64_t* __restrict__ src = operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, N);
+        int32_t av[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) av[i] = (int32_t)src[G::j_p1(lane, e0 + i)];
+        if (ad.op & ADD_CHECK) {   // fused norm predicate on this polynomial (needs the whole polynomial: CH == E)
+          uint64_t sq = 0;
+#pragma unroll
+          for (int i = 0; i < CH; ++i) {
+            uint32_t aa = (uint32_t)(av[i] < 0 ? -av[i] : av[i]);
+            aa = aa < (1u << 24) ? aa : (1u << 24);
+            sq += (uint64_t)aa * aa;
+          }
+          add_sq[a < 4 ? a : 3] += sq;
+        }
         if (ad.sign >= 0) {
 #pragma unroll
-          for (int i = 0; i < CH; ++i)
-            u[i] = addq(u[i], zq_from_centered((int32_t)src[G::j_p1(lane, e0 + i)], q), q);
+          for (int i = 0; i < CH; ++i) u[i] = addq(u[i], zq_from_centered(av[i], q), q);
         } else {
 #pragma unroll
-          for (int i = 0; i < CH; ++i)
-            u[i] = subq(u[i], zq_from_centered((int32_t)src[G::j_p1(lane, e0 + i)], q), q);
+          for (int i = 0; i < CH; ++i) u[i] = subq(u[i], zq_from_centered(av[i], q), q);
         }
       }
       if (row.mode == MODE_STORE) {
@@ -315,6 +342,19 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
     }
     if (row.mode != MODE_STORE) {
       if (__any(nz) && lane == 0) flags[bo] = 0;
+    }
+    if (ops.norm_limit) {
+      // checked additions: the host marks at most one checked addition per slot 0..3 of a row
+#pragma unroll 1
+      for (uint32_t a = 0; a < row.nadds && a < 4; ++a) {
+        if (prog->adds[row.add0 + a].op & ADD_CHECK) {
+          uint64_t tot = 0;
+#pragma unroll
+          for (int sl = 0; sl < 4; ++sl) tot = (sl == (int)a) ? add_sq[sl] : tot;
+          tot = wave_sum_u64(tot);
+          if (tot >= ops.norm_limit && lane == 0) flags[bo] = 0;
+        }
+      }
     }
   }
 }
@@ -557,7 +597,7 @@ row_kernel_small(const Program* __restrict__ prog, const Operands ops, const uin
     for (uint32_t t = 0; t < row.nterms; ++t) {
       const Term tm = prog->terms[row.term0 + t];
       const int64_t* __restrict__ pb = operand_ptr(ops, tm.b_op, tm.b_off, b, bo, (int)N);
-      if (tm.kind == TERM_KEY) {
+      if ((tm.kind & TERM_KIND_MASK) == TERM_KEY) {
         const uint32_t* __restrict__ km = key_mont + (size_t)tm.a_off * N;
         for (uint32_t i = lane; i < N; i += 64) {
           la[i] = zq_from_centered((int32_t)pb[i], q);
@@ -594,7 +634,7 @@ row_kernel_small(const Program* __restrict__ prog, const Operands ops, const uin
         uint32_t u = subq((uint32_t)(pos[e] % q), (uint32_t)(neg[e] % q), q);
         for (uint32_t a = 0; a < row.nadds; ++a) {
           const AddTerm ad = prog->adds[row.add0 + a];
-          const uint32_t v = zq_from_centered((int32_t)operand_ptr(ops, ad.op, ad.off, b, bo, (int)N)[tt], q);
+          const uint32_t v = zq_from_centered((int32_t)operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, (int)N)[tt], q);
           u = ad.sign >= 0 ? addq(u, v, q) : subq(u, v, q);
         }
         if (row.mode == MODE_STORE)

@@ -291,3 +291,72 @@ def test_sum_cycle_vs_oracle(torch_mod, shape):
         want = O.sum_verify(P, A, zst[b], zp[b], cs[b], cp[b], gs[b], ts[b], tp[b], u[b], d[b])
         assert int(acc[b]) == int(want == 1)
     assert acc.tolist() == [1, 0]
+
+
+def _four_squares(m):
+    """a^2+b^2+c^2+d^2 = m by search (Lagrange)."""
+    import math
+
+    a = math.isqrt(m)
+    while a >= 0:
+        r1 = m - a * a
+        b = math.isqrt(r1)
+        while b >= 0:
+            r2 = r1 - b * b
+            c = math.isqrt(r2)
+            while c >= 0 and c * c * 2 >= r2:
+                r3 = r2 - c * c
+                d = math.isqrt(r3)
+                if d * d == r3:
+                    return a, b, c, d
+                c -= 1
+            b -= 1
+            if (r1 - b * b) > 2 * (math.isqrt(r1) + 1) ** 2:
+                break
+        a -= 1
+    raise AssertionError("no decomposition")
+
+
+@pytest.mark.parametrize("N", [512, 1024])
+def test_fused_norm_predicate_exact_at_the_boundary(torch_mod, N):
+    """check_commit_constraint is fused into the commit rows: floor(sqrt(sum r^2)) <= bound must flip exactly
+    between sum = (bound+1)^2 - 1 and (bound+1)^2, for whichever polynomial of r carries the weight."""
+    ctx = ctx_for(N)
+    rng = np.random.default_rng(N + 1)
+    A = synth.key(rng, N, 1, 3, 1)
+    ctx.load_key(A)
+    Bd = ctx.commit_bound
+    a, b, c, d = _four_squares(2 * Bd)          # (Bd+1)^2 - 1 = Bd^2 + 2*Bd
+    cases = []
+    for col in range(3):                        # weight in r0 (identity column: an addition), r1, r2 (products)
+        r_ok = np.zeros((3, N), dtype=np.int64)
+        r_ok[col, :5] = [Bd, a, b, c, d]
+        assert O.norm2(r_ok[col]) == Bd and int((r_ok[col].astype(object) ** 2).sum()) == (Bd + 1) ** 2 - 1
+        r_bad = r_ok.copy()
+        r_bad[col, 7] = 1                       # sum = (Bd+1)^2 -> norm_2 = Bd + 1
+        assert O.norm2(r_bad[col]) == Bd + 1
+        r_huge = np.zeros((3, N), dtype=np.int64)
+        r_huge[col, 3] = (1 << 24) + 5          # above the clamp of the fused sum
+        cases += [(r_ok, 1), (r_bad, 0), (r_huge, 0)]
+    r = np.stack([cse[0] for cse in cases])
+    Bn = r.shape[0]
+    x = synth.uniform(rng, (Bn, 1, N))
+    y = synth.gauss(rng, (Bn, 3, N), ctx.sigma)
+    c_, t_, ok = ctx.open_commit(x, r, y)
+    assert ok.tolist() == [cse[1] for cse in cases]
+    P = _P(ctx)
+    for i in range(Bn):
+        c_ref, t_ref, ok_ref = O.open_commit(P, A, x[i], r[i], y[i])
+        assert bool(ok[i]) == ok_ref
+        assert np.array_equal(c_[i], c_ref) and np.array_equal(t_[i], t_ref)   # products stay exact either way
+    # the same predicate with the verify bound, fused into the verifier rows
+    Vb = ctx.verify_bound
+    a, b, c, d = _four_squares(2 * Vb)
+    z = np.zeros((2, 3, N), dtype=np.int64)
+    z[:, 2, :5] = [Vb, a, b, c, d]
+    z[1, 2, 9] = -1
+    tt = np.stack([O.mat_dot(A[:1], z[i][:, None, :])[:, 0, :] for i in range(2)])   # t := a1.z, c1 = 0 -> relation holds
+    cz = np.zeros((2, 2, N), dtype=np.int64)
+    dz = synth.challenge(rng, (2,), N, 36)
+    assert ctx.open_verify(z, tt, cz, dz).tolist() == [1, 0]
+    assert [int(O.open_verify(P, A, z[i], tt[i], cz[i], dz[i]) == 1) for i in range(2)] == [1, 0]

@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--shape", type=str, default="1,3,1", help="n,k,l")
     ap.add_argument("--summands", type=int, default=8, help="V for --workload sum")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target length of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=40.0, help="target length of the CPU baseline sample")
     return ap.parse_args()
 
 

@@ -96,13 +96,21 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
+    # RZK_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks
+    # share devices, reductions run on CPU tensors).  The real multi-GPU run uses nccl (= RCCL over xGMI).
+    backend = os.environ.get("RZK_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from ring_zk_amd import Context, shard, synth
 
@@ -110,8 +118,9 @@ def main():
     n, k, l = (int(v) for v in args.shape.split(","))
     V = args.summands
     B = args.batch
-    dev = torch.device("cuda", local_rank)
-    ctx = Context(N, n, k, l, device=local_rank)
+    dev = torch.device("cuda", dev_index)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")   # where the result reduction runs
+    ctx = Context(N, n, k, l, device=dev_index)
     sig = ctx.sigma
 
     # ---- synthetic inputs, generated directly in HBM; same key on every rank, different proofs per rank
@@ -194,7 +203,7 @@ def main():
     ok_cnt = int(ok.sum().item())
     assert accepted == B and ok_cnt == B, f"rank {rank}: {accepted}/{B} accepted, {ok_cnt}/{B} commit-ok"
 
-    elapsed, tot_acc = shard.reduce_result(dist, elapsed, accepted, dev)
+    elapsed, tot_acc = shard.reduce_result(dist, elapsed, accepted, red_dev)
     proofs = B * world * args.steps
     value = proofs / elapsed
 

@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -44,6 +45,10 @@ struct DevProg {
   Program* d = nullptr;
   uint32_t nrows = 0;
   bool has_vec = false;
+  // shared-operand path (fwd_slots_kernel + row_slots_kernel), chosen when rows share enough operands
+  SlotTable* d_slots = nullptr;
+  uint32_t nslots = 0;
+  uint32_t np_store = 0;
 };
 
 struct Arena {   // grow-only device buffer
@@ -77,7 +82,8 @@ struct rzk_ctx {
   uint32_t* d_key_ntt = nullptr;
   double* d_key_inf = nullptr;
   std::map<std::pair<int, uint32_t>, DevProg> progs;
-  Arena ws, stage;
+  Arena ws, stage, ws_slots;
+  double slot_share_min = 2.0;   // use the shared-operand path when (operand transforms) / (distinct operands) >= this
   std::string err;
   // profiling of the row kernel with HIP events on the launch stream
   bool prof = false;
@@ -411,14 +417,54 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
   HIPCHK(c, hipStreamSynchronize(c->stream));   // pb.p is a stack object; one-off per (program, shape)
   dp.nrows = pb.p.nrows;
   for (uint32_t t = 0; t < pb.p.nterms; ++t) dp.has_vec = dp.has_vec || (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_VEC;
+  // distinct operands of the product terms ("slots"); when rows share them often enough, transform each
+  // once per proof (shared-operand path) instead of once per row
+  if (!c->small && c->slot_share_min > 0 && pb.p.nterms > 0) {
+    std::vector<SlotTable> stv(1);
+    SlotTable& st = stv[0];
+    std::memset(&st, 0, sizeof(st));
+    std::map<std::pair<uint32_t, uint32_t>, uint32_t> index;
+    bool fits = true;
+    uint32_t transforms = 0;
+    auto slot_of = [&](uint8_t op, uint16_t off) -> uint32_t {
+      auto it = index.find({op, off});
+      if (it != index.end()) return it->second;
+      if (st.nslots >= (uint32_t)kMaxSlots) { fits = false; return 0; }
+      const uint32_t sidx = st.nslots++;
+      st.op[sidx] = op;
+      st.off[sidx] = off;
+      index[{op, off}] = sidx;
+      return sidx;
+    };
+    for (uint32_t t = 0; t < pb.p.nterms; ++t) {
+      const Term& tm = pb.p.terms[t];
+      const uint32_t sb = slot_of(tm.b_op, tm.b_off);
+      st.term_b[t] = (uint16_t)sb;
+      ++transforms;
+      if (tm.kind & TERM_CHECK) st.check[sb] = 1;
+      if ((tm.kind & TERM_KIND_MASK) == TERM_VEC) {
+        st.term_a[t] = (uint16_t)slot_of(tm.a_op, tm.a_off);
+        ++transforms;
+      }
+    }
+    if (fits && st.nslots > 0 && (double)transforms / st.nslots >= c->slot_share_min) {
+      HIPCHK(c, hipMalloc((void**)&dp.d_slots, sizeof(SlotTable)));
+      HIPCHK(c, hipMemcpyAsync(dp.d_slots, &st, sizeof(SlotTable), hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipStreamSynchronize(c->stream));
+      dp.nslots = st.nslots;
+      dp.np_store = dp.has_vec ? 3 : 2;
+    }
+  }
   c->progs[{id, var}] = dp;
   out = dp;
   return RZK_OK;
 }
 
 void drop_programs(rzk_ctx* c) {
-  for (auto& kv : c->progs)
+  for (auto& kv : c->progs) {
     if (kv.second.d) (void)hipFree(kv.second.d);
+    if (kv.second.d_slots) (void)hipFree(kv.second.d_slots);
+  }
   c->progs.clear();
 }
 
@@ -456,10 +502,38 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
     c->prof_used++;
     HIPCHK(c, hipEventRecord(e0, c->stream));
   }
-  int lrc = c->small ? launch_row_program_small(c->N, cfg_of(c), dp.d, dp.nrows, ops, c->d_key_mont, c->dT, c->r2q,
-                                                flags, batch)
-                     : launch_row_program((int)c->logn, cfg_of(c), dp.d, dp.nrows, dp.has_vec, ops, c->d_key_ntt,
-                                          c->d_key_inf, c->dT, c->d_tw, c->d_row_scratch, flags, batch);
+  int lrc = 0;
+  if (c->small) {
+    lrc = launch_row_program_small(c->N, cfg_of(c), dp.d, dp.nrows, ops, c->d_key_mont, c->dT, c->r2q, flags, batch);
+  } else if (dp.d_slots) {
+    // shared-operand path; the workspace of stored transforms is bounded, so large batches go in chunks
+    const size_t per_item = (size_t)dp.nslots * dp.np_store * c->N * sizeof(uint32_t) + (size_t)dp.nslots * 16;
+    const size_t cap = (size_t)6 << 30;
+    uint64_t chunk = cap / per_item;
+    const uint64_t grp = ops.group;
+    chunk -= chunk % grp;
+    if (chunk < grp) chunk = grp;
+    if (chunk > batch) chunk = batch;
+    int rc2 = arena_reserve(c, c->ws_slots, (size_t)chunk * per_item + 256);
+    if (rc2 != RZK_OK) return rc2;
+    uint32_t* d_ws = (uint32_t*)c->ws_slots.p;
+    double* d_norms = (double*)((char*)c->ws_slots.p + (((size_t)chunk * dp.nslots * dp.np_store * c->N * 4 + 255) & ~(size_t)255));
+    for (uint64_t b0 = 0; b0 < batch && lrc == 0; b0 += chunk) {
+      const uint64_t nb = batch - b0 < chunk ? batch - b0 : chunk;
+      Operands o2 = ops;
+      for (size_t i = 0; i < specs.size(); ++i) {
+        if (!o2.base[i]) continue;
+        const uint64_t first = o2.outer[i] ? b0 / grp : b0;
+        o2.base[i] += first * o2.stride[i] * c->N;
+      }
+      lrc = launch_row_program_slots((int)c->logn, cfg_of(c), dp.d, dp.d_slots, dp.nslots, o2, c->d_key_ntt,
+                                     c->d_key_inf, c->dT, c->d_tw, d_ws, d_norms, c->d_row_scratch,
+                                     flags ? flags + b0 / grp : nullptr, nb, dp.np_store);
+    }
+  } else {
+    lrc = launch_row_program((int)c->logn, cfg_of(c), dp.d, dp.nrows, dp.has_vec, ops, c->d_key_ntt, c->d_key_inf,
+                             c->dT, c->d_tw, c->d_row_scratch, flags, batch);
+  }
   if (lrc == -2) return fail(c, RZK_E_UNSUPPORTED, "batch * rows must stay below 2^32");
   if (lrc != 0) {
     c->err = std::string("row kernel launch: ") + (lrc > 0 ? hipGetErrorString((hipError_t)lrc) : "bad ring degree");
@@ -599,6 +673,7 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
     return create_fail(RZK_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(de));
   }
   c->stream = c->own_stream;
+  if (const char* e = std::getenv("RZK_SLOT_SHARE_MIN")) c->slot_share_min = std::atof(e);   // tuning knob
   // twiddle tables: 3 primes x {fwd, inv} x kTableLen
   std::vector<uint32_t> all((size_t)2 * kMaxPrimes * kTableLen);
   for (int i = 0; i < kMaxPrimes; ++i) {
@@ -636,6 +711,7 @@ void rzk_ctx_destroy(rzk_ctx* c) {
   if (c->d_key_ntt) (void)hipFree(c->d_key_ntt);
   if (c->d_key_inf) (void)hipFree(c->d_key_inf);
   if (c->ws.p) (void)hipFree(c->ws.p);
+  if (c->ws_slots.p) (void)hipFree(c->ws_slots.p);
   if (c->stage.p) (void)hipFree(c->stage.p);
   if (c->dT) (void)hipFree(c->dT);
   if (c->d_tw) (void)hipFree(c->d_tw);

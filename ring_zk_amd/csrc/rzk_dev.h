@@ -66,6 +66,16 @@ struct Program {
   AddTerm adds[kMaxAdds];
 };
 
+// Shared-operand path: the distinct polynomials ("slots") the product terms of a program read, and for
+// each term the slots of its operands.  check[s] != 0: the slot belongs to a norm-checked vector.
+constexpr int kMaxSlots = 512;
+struct SlotTable {
+  uint32_t nslots, pad;
+  uint16_t op[kMaxSlots], off[kMaxSlots];
+  uint8_t check[kMaxSlots];
+  uint16_t term_a[kMaxTerms], term_b[kMaxTerms];
+};
+
 // Operand table of one launch.  The batch index b of a task may be a (proof, summand) pair:
 // bo = b / group is the proof.  Polynomial (op, off) lives at
 // base[op] + ((outer[op] ? bo : b) * stride[op] + off) * N ; verification flags are per proof (flags[bo]).
@@ -88,6 +98,11 @@ int launch_row_program(int logn, const LaunchCfg& cfg, const Program* d_prog, ui
                        const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf,
                        const DevTables* d_T, const uint32_t* d_tw, uint32_t* d_scratch, uint8_t* d_flags,
                        uint64_t batch);
+int launch_row_program_slots(int logn, const LaunchCfg& cfg, const Program* d_prog, const SlotTable* d_slots,
+                             uint32_t nslots, const Operands& ops, const uint32_t* d_key_ntt,
+                             const double* d_key_inf, const DevTables* d_T, const uint32_t* d_tw, uint32_t* d_ws,
+                             double* d_norms, uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch,
+                             uint32_t np_store);
 // words of per-wave global scratch the row kernel needs: (max blocks) * 4 waves * N
 size_t row_scratch_words(int logn, int num_cus);
 int launch_key_transform(int logn, const LaunchCfg& cfg, const int64_t* d_key, uint32_t entries,

@@ -145,18 +145,211 @@ __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict
 }
 
 // =============================================================================================
-// Row-program kernel: the fused product / accumulate / reduce pipeline of every protocol phase.
+// Row-program kernels: the fused product / accumulate / reduce pipeline of every protocol phase.
 //
 // One wavefront evaluates one output row of one proof (rzk_dev.h).  Control flow is wave-uniform
 // and scalar (the wave index is read with readfirstlane).  Primes are processed one after the
-// other; the operands' norms are measured while they are loaded for the first prime, which fixes
-// how many primes (1..3) the exact result needs before any residue is folded into the running
-// Garner state (rzk_core.h, crt_fold*), so only two words per coefficient stay live across primes.
-// HAS_VEC = false is the lean instance for programs made of key products only.
+// other; each inverse transform is folded at once into the running Garner state (rzk_core.h,
+// crt_fold*), which lives in LDS (word A) and, for a third prime only, in a per-wave global
+// scratch line (word B), so no state occupies registers during the transforms.
+//
+//   row_kernel        transforms the operands of every term inside the wave; the operands' norms are
+//                     measured while they are loaded for the first prime, which fixes how many primes
+//                     (1..3) the exact result needs.  Best when rows share few operands ((n,k,l)=(1,3,1)).
+//   fwd_slots_kernel  + row_slots_kernel: when many rows of a proof use the same operands (key blocks
+//                     with n > 1, sums over V summands), every distinct operand ("slot") is transformed
+//                     ONCE per proof into a workspace in HBM (L2-resident per proof), and the rows only
+//                     multiply-accumulate the stored transforms; rows that need more primes than were
+//                     stored fall back to in-wave transforms for the missing primes, so results stay exact.
 // =============================================================================================
 #ifndef RZK_ROW_MIN_WAVES
-#define RZK_ROW_MIN_WAVES 1   // minimum waves per SIMD the row kernel is compiled for (register budget)
+#define RZK_ROW_MIN_WAVES 1   // minimum waves per SIMD the row kernels are compiled for (register budget)
 #endif
+
+// acc +/- (term) for prime `pi`, transforming the term's operands in the wave.
+template <int LOGN, bool HAS_VEC>
+__device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const Operands& ops, uint32_t b,
+                                            uint32_t bo, int lane, uint32_t* lds, const uint32_t* __restrict__ twf,
+                                            const PrimeConsts& pc, int pi, const uint32_t* __restrict__ key_ntt,
+                                            const double* __restrict__ key_inf, bool first, double& bound,
+                                            uint8_t* __restrict__ flags) {
+  using G = Geo<LOGN>;
+  constexpr int E = G::E;
+  constexpr int N = G::N;
+  // optional opaque copy of the lane id (RZK_OPAQUE): stops hoisting of lane-dependent addresses
+  int ln = lane;
+  RZK_OPAQUE(ln);
+  uint32_t x[E];
+  double l1b = 0, infb = 0;
+  uint64_t sumsq = 0;
+  const bool chk = first && (tm.kind & TERM_CHECK);
+  load_lift<LOGN>(x, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), ln, pc, first, l1b, infb, chk, sumsq);
+  if (chk && sumsq >= ops.norm_limit && lane == 0) flags[bo] = 0;
+  wave_fwd<LOGN>(x, ln, lds, twf, pc);
+  if (HAS_VEC && (tm.kind & TERM_KIND_MASK) == TERM_VEC) {
+    // product of two per-proof polynomials: fold N^-1 and the Montgomery factor into one of them
+    uint32_t xb[E];
+#pragma unroll
+    for (int c = 0; c < E; ++c) xb[c] = csub(mont_lazy(x[c], pc.ninv_r2, pc.p, pc.npinv), pc.p);
+    double l1a = 0, infa = 0;
+    uint64_t unused_sq = 0;
+    load_lift<LOGN>(x, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), ln, pc, first, l1a, infa, false, unused_sq);
+    wave_fwd<LOGN>(x, ln, lds, twf, pc);
+    if (first) {
+      const double u = l1a * infb, v = infa * l1b;
+      bound += u < v ? u : v;
+    }
+    if (tm.sign >= 0) {
+#pragma unroll
+      for (int c = 0; c < E; ++c) acc[c] = mac_add(acc[c], x[c], xb[c], pc);
+    } else {
+#pragma unroll
+      for (int c = 0; c < E; ++c) acc[c] = mac_sub(acc[c], x[c], xb[c], pc);
+    }
+  } else {
+    if (first) bound += key_inf[tm.a_off] * l1b;
+    const uint4* __restrict__ kp = reinterpret_cast<const uint4*>(key_ntt + ((size_t)tm.a_off * kMaxPrimes + pi) * N);
+    if (tm.sign >= 0) {
+#pragma unroll
+      for (int g = 0; g < E / 4; ++g) {
+        const uint4 kv = kp[g * 64 + ln];
+        acc[4 * g + 0] = mac_add(acc[4 * g + 0], x[4 * g + 0], kv.x, pc);
+        acc[4 * g + 1] = mac_add(acc[4 * g + 1], x[4 * g + 1], kv.y, pc);
+        acc[4 * g + 2] = mac_add(acc[4 * g + 2], x[4 * g + 2], kv.z, pc);
+        acc[4 * g + 3] = mac_add(acc[4 * g + 3], x[4 * g + 3], kv.w, pc);
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < E / 4; ++g) {
+        const uint4 kv = kp[g * 64 + ln];
+        acc[4 * g + 0] = mac_sub(acc[4 * g + 0], x[4 * g + 0], kv.x, pc);
+        acc[4 * g + 1] = mac_sub(acc[4 * g + 1], x[4 * g + 1], kv.y, pc);
+        acc[4 * g + 2] = mac_sub(acc[4 * g + 2], x[4 * g + 2], kv.z, pc);
+        acc[4 * g + 3] = mac_sub(acc[4 * g + 3], x[4 * g + 3], kv.w, pc);
+      }
+    }
+  }
+}
+
+// inverse transform of the prime-`pi` accumulator and fold into the Garner state: word A in LDS, word B
+// (third prime only) in the per-wave global scratch line.  acc is clobbered.
+template <int LOGN>
+__device__ __forceinline__ void inverse_and_fold(int pi, int np, uint32_t* acc, int lane, uint32_t* lds,
+                                                 const uint32_t* __restrict__ twi, const PrimeConsts& pc,
+                                                 uint32_t* st_lds, uint32_t* __restrict__ st_glb, const DevTables& T) {
+  using G = Geo<LOGN>;
+  constexpr int E = G::E;
+  int li = lane;
+  RZK_OPAQUE(li);
+  wave_inv<LOGN>(acc, li, lds, twi, pc);
+  if (pi == 0) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) st_lds[G::j_p1(li, e)] = crt_fold0(acc[e], np, T.pc, T.crt);
+  } else if (pi == 1) {
+    uint32_t d0[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      d0[e] = st_lds[G::j_p1(li, e)];
+      acc[e] = crt_digit1(acc[e], d0[e], np, T.pc, T.crt);
+    }
+    if (np == 3) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) st_glb[G::j_p1(li, e)] = crt_value01_modp2(d0[e], acc[e], T.pc, T.crt);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) st_lds[G::j_p1(li, e)] = crt_value01_modq(d0[e], acc[e], T.crt);
+  } else {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      uint32_t a = st_lds[G::j_p1(li, e)];
+      crt_fold2(acc[e], T.pc, T.crt, a, st_glb[G::j_p1(li, e)]);
+      st_lds[G::j_p1(li, e)] = a;
+    }
+  }
+}
+
+// plain additions in 32-bit arithmetic mod q, then centre and store / zero test; RZK_EPI_CHUNK coefficients
+// per lane at a time.  Checked additions also evaluate the fused norm predicate.
+template <int LOGN>
+__device__ __forceinline__ void row_epilogue(const Program* __restrict__ prog, const Row row, const Operands& ops,
+                                             uint32_t b, uint32_t bo, int lane, bool has_terms, int np,
+                                             const uint32_t* st_lds, const DevTables& T, uint8_t* __restrict__ flags) {
+  using G = Geo<LOGN>;
+  constexpr int E = G::E;
+  constexpr int N = G::N;
+  int nz = 0;
+  constexpr int CH = RZK_EPI_CHUNK < E ? RZK_EPI_CHUNK : E;
+  const uint32_t q = T.crt.q;
+  uint64_t add_sq[4] = {0, 0, 0, 0};   // per-lane partial sums of squares of checked additions (slot = add index)
+#pragma unroll
+  for (int e0 = 0; e0 < E; e0 += CH) {
+    uint32_t u[CH];
+    if (has_terms) {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) u[i] = crt_finish_zq(st_lds[G::j_p1(lane, e0 + i)], np, T.crt);
+    } else {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) u[i] = 0;
+    }
+#pragma unroll 1
+    for (uint32_t a = 0; a < row.nadds; ++a) {
+      const AddTerm ad = prog->adds[row.add0 + a];
+      const int64_t* __restrict__ src = operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, N);
+      int32_t av[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) av[i] = (int32_t)src[G::j_p1(lane, e0 + i)];
+      if (ad.op & ADD_CHECK) {
+        uint64_t sq = 0;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          uint32_t aa = (uint32_t)(av[i] < 0 ? -av[i] : av[i]);
+          aa = aa < (1u << 24) ? aa : (1u << 24);
+          sq += (uint64_t)aa * aa;
+        }
+        add_sq[a < 4 ? a : 3] += sq;
+      }
+      if (ad.sign >= 0) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) u[i] = addq(u[i], zq_from_centered(av[i], q), q);
+      } else {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) u[i] = subq(u[i], zq_from_centered(av[i], q), q);
+      }
+    }
+    if (row.mode == MODE_STORE) {
+      int64_t* __restrict__ dst = const_cast<int64_t*>(operand_ptr(ops, row.out_op, row.out_off, b, bo, N));
+#pragma unroll
+      for (int i = 0; i < CH; ++i) dst[G::j_p1(lane, e0 + i)] = center_from_zq(u[i], T.crt);
+    } else {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) nz |= (u[i] != 0);
+    }
+  }
+  if (row.mode != MODE_STORE) {
+    if (__any(nz) && lane == 0) flags[bo] = 0;
+  }
+  if (ops.norm_limit) {
+    // checked additions: the host marks them only among the first four additions of a row
+#pragma unroll 1
+    for (uint32_t a = 0; a < row.nadds && a < 4; ++a) {
+      if (prog->adds[row.add0 + a].op & ADD_CHECK) {
+        uint64_t tot = 0;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) tot = (sl == (int)a) ? add_sq[sl] : tot;
+        tot = wave_sum_u64(tot);
+        if (tot >= ops.norm_limit && lane == 0) flags[bo] = 0;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ int primes_for(double bound, const DevTables& T) {
+  // |exact result| <= bound: the smallest prime count whose range covers it
+  bound *= 1.0 + 1e-9;   // the double products are rounded; stay on the safe side
+  const int np = bound <= T.cap[1] ? 1 : (bound <= T.cap[2] ? 2 : 3);
+  return __builtin_amdgcn_readfirstlane(np);
+}
+
 template <int LOGN, bool HAS_VEC>
 __global__ void __launch_bounds__(256, RZK_ROW_MIN_WAVES)
 row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t* __restrict__ key_ntt,
@@ -189,173 +382,190 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
       for (int pi = 0; pi < np; ++pi) {
         const PrimeConsts pc = T.pc[pi];
         const uint32_t* __restrict__ twf = tw_all + (size_t)(2 * pi) * kTableLen;
-        const uint32_t* __restrict__ twi = twf + kTableLen;
         const bool first = pi == 0;
         uint32_t acc[E];
 #pragma unroll
         for (int c = 0; c < E; ++c) acc[c] = 0;
 #pragma unroll 1
-        for (uint32_t t = 0; t < row.nterms; ++t) {
-          const Term tm = prog->terms[row.term0 + t];
-          // optional opaque copy of the lane id (RZK_OPAQUE_LANE): stops hoisting of lane-dependent addresses
-          int ln = lane;
-          RZK_OPAQUE(ln);
-          uint32_t x[E];
-          double l1b = 0, infb = 0;
-          uint64_t sumsq = 0;
-          const bool chk = first && (tm.kind & TERM_CHECK);
-          load_lift<LOGN>(x, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), ln, pc, first, l1b, infb, chk, sumsq);
-          if (chk && sumsq >= ops.norm_limit && lane == 0) flags[bo] = 0;
-          wave_fwd<LOGN>(x, ln, lds, twf, pc);
-          if (HAS_VEC && (tm.kind & TERM_KIND_MASK) == TERM_VEC) {
-            // product of two per-proof polynomials: fold N^-1 and the Montgomery factor into one of them
-            uint32_t xb[E];
-#pragma unroll
-            for (int c = 0; c < E; ++c) xb[c] = csub(mont_lazy(x[c], pc.ninv_r2, pc.p, pc.npinv), pc.p);
-            double l1a = 0, infa = 0;
-            uint64_t unused_sq = 0;
-            load_lift<LOGN>(x, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), ln, pc, first, l1a, infa, false, unused_sq);
-            wave_fwd<LOGN>(x, ln, lds, twf, pc);
-            if (first) {
-              const double u = l1a * infb, v = infa * l1b;
-              bound += u < v ? u : v;
-            }
-            if (tm.sign >= 0) {
-#pragma unroll
-              for (int c = 0; c < E; ++c) acc[c] = mac_add(acc[c], x[c], xb[c], pc);
-            } else {
-#pragma unroll
-              for (int c = 0; c < E; ++c) acc[c] = mac_sub(acc[c], x[c], xb[c], pc);
-            }
-          } else {
-            if (first) bound += key_inf[tm.a_off] * l1b;
-            const uint4* __restrict__ kp =
-                reinterpret_cast<const uint4*>(key_ntt + ((size_t)tm.a_off * kMaxPrimes + pi) * N);
-            if (tm.sign >= 0) {
-#pragma unroll
-              for (int g = 0; g < E / 4; ++g) {
-                const uint4 kv = kp[g * 64 + ln];
-                acc[4 * g + 0] = mac_add(acc[4 * g + 0], x[4 * g + 0], kv.x, pc);
-                acc[4 * g + 1] = mac_add(acc[4 * g + 1], x[4 * g + 1], kv.y, pc);
-                acc[4 * g + 2] = mac_add(acc[4 * g + 2], x[4 * g + 2], kv.z, pc);
-                acc[4 * g + 3] = mac_add(acc[4 * g + 3], x[4 * g + 3], kv.w, pc);
-              }
-            } else {
-#pragma unroll
-              for (int g = 0; g < E / 4; ++g) {
-                const uint4 kv = kp[g * 64 + ln];
-                acc[4 * g + 0] = mac_sub(acc[4 * g + 0], x[4 * g + 0], kv.x, pc);
-                acc[4 * g + 1] = mac_sub(acc[4 * g + 1], x[4 * g + 1], kv.y, pc);
-                acc[4 * g + 2] = mac_sub(acc[4 * g + 2], x[4 * g + 2], kv.z, pc);
-                acc[4 * g + 3] = mac_sub(acc[4 * g + 3], x[4 * g + 3], kv.w, pc);
-              }
-            }
-          }
-        }
-        if (first) {
-          // |exact result| <= bound: pick the smallest prime count whose range covers it
-          bound *= 1.0 + 1e-9;   // the double products are rounded; stay on the safe side
-          np = bound <= T.cap[1] ? 1 : (bound <= T.cap[2] ? 2 : 3);
-          np = __builtin_amdgcn_readfirstlane(np);
-        }
-        int li = lane;
-        RZK_OPAQUE(li);
-        wave_inv<LOGN>(acc, li, lds, twi, pc);
-        // fold this prime's residues into the Garner state: word A lives in LDS, word B (third prime
-        // only) in a per-wave global scratch line, so neither occupies registers during the transforms
-        if (pi == 0) {
-#pragma unroll
-          for (int e = 0; e < E; ++e) st_lds[G::j_p1(li, e)] = crt_fold0(acc[e], np, T.pc, T.crt);
-        } else if (pi == 1) {
-          uint32_t d0[E];
-#pragma unroll
-          for (int e = 0; e < E; ++e) {
-            d0[e] = st_lds[G::j_p1(li, e)];
-            acc[e] = crt_digit1(acc[e], d0[e], np, T.pc, T.crt);
-          }
-          if (np == 3) {
-#pragma unroll
-            for (int e = 0; e < E; ++e) st_glb[G::j_p1(li, e)] = crt_value01_modp2(d0[e], acc[e], T.pc, T.crt);
-          }
-#pragma unroll
-          for (int e = 0; e < E; ++e) st_lds[G::j_p1(li, e)] = crt_value01_modq(d0[e], acc[e], T.crt);
-        } else {
-#pragma unroll
-          for (int e = 0; e < E; ++e) {
-            uint32_t a = st_lds[G::j_p1(li, e)];
-            crt_fold2(acc[e], T.pc, T.crt, a, st_glb[G::j_p1(li, e)]);
-            st_lds[G::j_p1(li, e)] = a;
-          }
-        }
+        for (uint32_t t = 0; t < row.nterms; ++t)
+          term_direct<LOGN, HAS_VEC>(acc, prog->terms[row.term0 + t], ops, b, bo, lane, lds, twf, pc, pi, key_ntt,
+                                     key_inf, first, bound, flags);
+        if (first) np = primes_for(bound, T);
+        inverse_and_fold<LOGN>(pi, np, acc, lane, lds, twf + kTableLen, pc, st_lds, st_glb, T);
       }
     }
+    row_epilogue<LOGN>(prog, row, ops, b, bo, lane, has_terms, np, st_lds, T, flags);
+  }
+}
 
-    // plain additions in 32-bit arithmetic mod q, then centre and store / zero test; RZK_EPI_CHUNK
-    // coefficients per lane at a time
-    int nz = 0;
-    constexpr int CH = RZK_EPI_CHUNK < E ? RZK_EPI_CHUNK : E;
-    const uint32_t q = T.crt.q;
-    uint64_t add_sq[4] = {0, 0, 0, 0};   // per-lane partial sums of squares of checked additions (slot = add index)
+// ---- shared-operand path ------------------------------------------------------------------------------------
+// Forward pass: one wavefront per (proof, slot) transforms the slot's polynomial for the first `np_store`
+// primes into ws[((b*nslots + s)*np_store + pi)*N ...] (canonical residues, NTT-domain layout) and records
+// its 1-norm / max-norm in norms[(b*nslots + s)*2 ..]; slots of a checked vector also evaluate the fused
+// norm predicate.
+template <int LOGN>
+__global__ void __launch_bounds__(256)
+fwd_slots_kernel(const SlotTable* __restrict__ slots, const Operands ops, const DevTables* __restrict__ Tp,
+                 const uint32_t* __restrict__ tw_all, uint32_t* __restrict__ ws, double* __restrict__ norms,
+                 uint8_t* __restrict__ flags, const uint32_t ntasks, const uint32_t np_store) {
+  using G = Geo<LOGN>;
+  constexpr int E = G::E;
+  constexpr int N = G::N;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t* lds = smem + wave * G::LDS_WORDS;
+  const DevTables& T = *Tp;
+  const uint32_t nslots = slots->nslots;
+  for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
+    const uint32_t b = task / nslots;
+    const uint32_t s = task - b * nslots;
+    const uint32_t bo = ops.group > 1 ? b / ops.group : b;
+    const int64_t* __restrict__ src = operand_ptr(ops, slots->op[s], slots->off[s], b, bo, N);
+    int32_t v[E];
 #pragma unroll
-    for (int e0 = 0; e0 < E; e0 += CH) {
-      uint32_t u[CH];
-      if (has_terms) {
+    for (int e = 0; e < E; ++e) v[e] = (int32_t)src[G::j_p1(lane, e)];
+    uint64_t sum = 0, sq = 0;
+    uint32_t mx = 0;
 #pragma unroll
-        for (int i = 0; i < CH; ++i) u[i] = crt_finish_zq(st_lds[G::j_p1(lane, e0 + i)], np, T.crt);
-      } else {
-#pragma unroll
-        for (int i = 0; i < CH; ++i) u[i] = 0;
-      }
+    for (int e = 0; e < E; ++e) {
+      const uint32_t a = (uint32_t)(v[e] < 0 ? -v[e] : v[e]);
+      sum += a;
+      mx = a > mx ? a : mx;
+      const uint32_t ac = a < (1u << 24) ? a : (1u << 24);
+      sq += (uint64_t)ac * ac;
+    }
+    const double l1 = (double)wave_sum_u64(sum);
+    const double linf = (double)wave_max_u32(mx);
+    if (lane == 0) {
+      norms[((size_t)b * nslots + s) * 2 + 0] = l1;
+      norms[((size_t)b * nslots + s) * 2 + 1] = linf;
+    }
+    if (slots->check[s] && ops.norm_limit) {
+      if (wave_sum_u64(sq) >= ops.norm_limit && lane == 0) flags[bo] = 0;
+    }
 #pragma unroll 1
-      for (uint32_t a = 0; a < row.nadds; ++a) {
-        const AddTerm ad = prog->adds[row.add0 + a];
-        const int64_t* __restrict__ src = operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, N);
-        int32_t av[CH];
+    for (uint32_t pi = 0; pi < np_store; ++pi) {
+      const PrimeConsts pc = T.pc[pi];
+      uint32_t x[E];
 #pragma unroll
-        for (int i = 0; i < CH; ++i) av[i] = (int32_t)src[G::j_p1(lane, e0 + i)];
-        if (ad.op & ADD_CHECK) {   // fused norm predicate on this polynomial (needs the whole polynomial: CH == E)
-          uint64_t sq = 0;
+      for (int e = 0; e < E; ++e) x[e] = lift(v[e], pc);
+      wave_fwd<LOGN>(x, lane, lds, tw_all + (size_t)(2 * pi) * kTableLen, pc);
+      uint4* __restrict__ dst = reinterpret_cast<uint4*>(ws + (((size_t)b * nslots + s) * np_store + pi) * N);
 #pragma unroll
-          for (int i = 0; i < CH; ++i) {
-            uint32_t aa = (uint32_t)(av[i] < 0 ? -av[i] : av[i]);
-            aa = aa < (1u << 24) ? aa : (1u << 24);
-            sq += (uint64_t)aa * aa;
-          }
-          add_sq[a < 4 ? a : 3] += sq;
-        }
-        if (ad.sign >= 0) {
-#pragma unroll
-          for (int i = 0; i < CH; ++i) u[i] = addq(u[i], zq_from_centered(av[i], q), q);
+      for (int g = 0; g < E / 4; ++g) {
+        uint4 o;
+        o.x = csub(csub(x[4 * g + 0], pc.twop), pc.p);
+        o.y = csub(csub(x[4 * g + 1], pc.twop), pc.p);
+        o.z = csub(csub(x[4 * g + 2], pc.twop), pc.p);
+        o.w = csub(csub(x[4 * g + 3], pc.twop), pc.p);
+        dst[g * 64 + lane] = o;
+      }
+    }
+  }
+}
+
+// Row pass of the shared-operand path.  Work is dealt so that all rows of a proof run on workgroups
+// whose ids are congruent mod 8 (one XCD under the observed round-robin placement: the proof's stored
+// transforms then come from that XCD's L2; placement affects speed only, never results).
+template <int LOGN>
+__global__ void __launch_bounds__(256, RZK_ROW_MIN_WAVES)
+row_slots_kernel(const Program* __restrict__ prog, const SlotTable* __restrict__ slots, const Operands ops,
+                 const uint32_t* __restrict__ key_ntt, const double* __restrict__ key_inf,
+                 const DevTables* __restrict__ Tp, const uint32_t* __restrict__ tw_all,
+                 const uint32_t* __restrict__ ws, const double* __restrict__ norms, uint32_t* __restrict__ scratch,
+                 uint8_t* __restrict__ flags, const uint32_t batch, const uint32_t np_store) {
+  using G = Geo<LOGN>;
+  constexpr int E = G::E;
+  constexpr int N = G::N;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t* lds = smem + wave * G::LDS_WORDS;
+  uint32_t* st_lds = smem + 4 * G::LDS_WORDS + wave * N;
+  uint32_t* st_glb = scratch + ((size_t)blockIdx.x * 4 + wave) * N;
+  const DevTables& T = *Tp;
+  const uint32_t nrows = prog->nrows;
+  const uint32_t nslots = slots->nslots;
+  const uint32_t groups = (nrows + 3) / 4;                 // row groups (4 rows, one per wave) per proof
+  // item stream of this workgroup's XCD class: proofs xcd, xcd+8, ... ; each proof contributes `groups` items
+  const uint32_t xcd = blockIdx.x & 7, lane_blocks = (gridDim.x + 7 - xcd) / 8;   // workgroups in this class
+  const uint32_t proofs_here = batch > xcd ? (batch - xcd + 7) / 8 : 0;
+  const uint32_t items = proofs_here * groups;
+  for (uint32_t item = blockIdx.x >> 3; item < items; item += lane_blocks) {
+    const uint32_t b = xcd + 8 * (item / groups);
+    const uint32_t rowi = (item % groups) * 4 + wave;
+    if (rowi >= nrows) continue;
+    const uint32_t bo = ops.group > 1 ? b / ops.group : b;
+    const Row row = prog->rows[rowi];
+    const bool has_terms = row.nterms > 0;
+    int np = 1;
+    if (has_terms) {
+      const double* __restrict__ nb = norms + (size_t)b * nslots * 2;
+      double bound = 0.0;
+#pragma unroll 1
+      for (uint32_t t = 0; t < row.nterms; ++t) {
+        const Term tm = prog->terms[row.term0 + t];
+        const uint32_t sb = slots->term_b[row.term0 + t];
+        if ((tm.kind & TERM_KIND_MASK) == TERM_VEC) {
+          const uint32_t sa = slots->term_a[row.term0 + t];
+          const double u = nb[2 * sa] * nb[2 * sb + 1], v = nb[2 * sa + 1] * nb[2 * sb];
+          bound += u < v ? u : v;
         } else {
-#pragma unroll
-          for (int i = 0; i < CH; ++i) u[i] = subq(u[i], zq_from_centered(av[i], q), q);
+          bound += key_inf[tm.a_off] * nb[2 * sb];
         }
       }
-      if (row.mode == MODE_STORE) {
-        int64_t* __restrict__ dst = const_cast<int64_t*>(operand_ptr(ops, row.out_op, row.out_off, b, bo, N));
-#pragma unroll
-        for (int i = 0; i < CH; ++i) dst[G::j_p1(lane, e0 + i)] = center_from_zq(u[i], T.crt);
-      } else {
-#pragma unroll
-        for (int i = 0; i < CH; ++i) nz |= (u[i] != 0);
-      }
-    }
-    if (row.mode != MODE_STORE) {
-      if (__any(nz) && lane == 0) flags[bo] = 0;
-    }
-    if (ops.norm_limit) {
-      // checked additions: the host marks at most one checked addition per slot 0..3 of a row
+      np = primes_for(bound, T);
 #pragma unroll 1
-      for (uint32_t a = 0; a < row.nadds && a < 4; ++a) {
-        if (prog->adds[row.add0 + a].op & ADD_CHECK) {
-          uint64_t tot = 0;
+      for (int pi = 0; pi < np; ++pi) {
+        const PrimeConsts pc = T.pc[pi];
+        const uint32_t* __restrict__ twf = tw_all + (size_t)(2 * pi) * kTableLen;
+        uint32_t acc[E];
 #pragma unroll
-          for (int sl = 0; sl < 4; ++sl) tot = (sl == (int)a) ? add_sq[sl] : tot;
-          tot = wave_sum_u64(tot);
-          if (tot >= ops.norm_limit && lane == 0) flags[bo] = 0;
+        for (int c = 0; c < E; ++c) acc[c] = 0;
+        if ((uint32_t)pi < np_store) {
+          // stored transforms: multiply-accumulate only
+#pragma unroll 1
+          for (uint32_t t = 0; t < row.nterms; ++t) {
+            const Term tm = prog->terms[row.term0 + t];
+            const uint4* __restrict__ xb = reinterpret_cast<const uint4*>(
+                ws + (((size_t)b * nslots + slots->term_b[row.term0 + t]) * np_store + pi) * N);
+            const bool vec = (tm.kind & TERM_KIND_MASK) == TERM_VEC;
+            const uint4* __restrict__ other =
+                vec ? reinterpret_cast<const uint4*>(
+                          ws + (((size_t)b * nslots + slots->term_a[row.term0 + t]) * np_store + pi) * N)
+                    : reinterpret_cast<const uint4*>(key_ntt + ((size_t)tm.a_off * kMaxPrimes + pi) * N);
+#pragma unroll
+            for (int g = 0; g < E / 4; ++g) {
+              const uint4 xv = xb[g * 64 + lane];
+              const uint4 ov = other[g * 64 + lane];
+              uint32_t xs[4] = {xv.x, xv.y, xv.z, xv.w};
+              const uint32_t os[4] = {ov.x, ov.y, ov.z, ov.w};
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                uint32_t w = os[i];
+                if (vec) {   // x_a * x_b * N^-1: two Montgomery steps (the key already carries N^-1 * R)
+                  xs[i] = mont_lazy(xs[i], os[i], pc.p, pc.npinv);
+                  w = pc.ninv_r2;
+                }
+                acc[4 * g + i] = tm.sign >= 0 ? mac_add(acc[4 * g + i], xs[i], w, pc) : mac_sub(acc[4 * g + i], xs[i], w, pc);
+              }
+            }
+          }
+        } else {
+          // more primes needed than were stored: transform in the wave for the missing ones
+          double unused = 0.0;
+#pragma unroll 1
+          for (uint32_t t = 0; t < row.nterms; ++t) {
+            Term tm = prog->terms[row.term0 + t];
+            tm.kind &= TERM_KIND_MASK;   // norm predicate already evaluated by the forward pass
+            term_direct<LOGN, true>(acc, tm, ops, b, bo, lane, lds, twf, pc, pi, key_ntt, key_inf, false, unused, flags);
+          }
         }
+        inverse_and_fold<LOGN>(pi, np, acc, lane, lds, twf + kTableLen, pc, st_lds, st_glb, T);
       }
     }
+    row_epilogue<LOGN>(prog, row, ops, b, bo, lane, has_terms, np, st_lds, T, flags);
   }
 }
 
@@ -761,6 +971,41 @@ int launch_row_program(int logn, const LaunchCfg& cfg, const Program* d_prog, ui
     RZK_ROW_CASE(11)
   }
 #undef RZK_ROW_CASE
+  return -1;
+}
+
+template <int LOGN>
+static int launch_slots_t(const LaunchCfg& cfg, const Program* d_prog, const SlotTable* d_slots, uint32_t nslots,
+                          const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T,
+                          const uint32_t* d_tw, uint32_t* d_ws, double* d_norms, uint32_t* d_scratch, uint8_t* d_flags,
+                          uint32_t batch, uint32_t np_store) {
+  using G = Geo<LOGN>;
+  const uint32_t ftasks = batch * nslots;
+  hipLaunchKernelGGL(fwd_slots_kernel<LOGN>, dim3(grid_for(ftasks, cfg.num_cus)), dim3(256),
+                     4 * G::LDS_WORDS * sizeof(uint32_t), (hipStream_t)cfg.stream, d_slots, ops, T, d_tw, d_ws, d_norms,
+                     d_flags, ftasks, np_store);
+  RZK_LAUNCH_CHECK();
+  unsigned grid = (unsigned)cfg.num_cus * 8;   // multiple of 8: the XCD-class dealing needs whole classes
+  grid -= grid % 8;
+  hipLaunchKernelGGL(row_slots_kernel<LOGN>, dim3(grid), dim3(256), 4 * (G::LDS_WORDS + G::N) * sizeof(uint32_t),
+                     (hipStream_t)cfg.stream, d_prog, d_slots, ops, d_key_ntt, d_key_inf, T, d_tw, d_ws, d_norms,
+                     d_scratch, d_flags, batch, np_store);
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_row_program_slots(int logn, const LaunchCfg& cfg, const Program* d_prog, const SlotTable* d_slots,
+                             uint32_t nslots, const Operands& ops, const uint32_t* d_key_ntt,
+                             const double* d_key_inf, const DevTables* T, const uint32_t* d_tw, uint32_t* d_ws,
+                             double* d_norms, uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch,
+                             uint32_t np_store) {
+  if (batch == 0) return 0;
+  if (batch * nslots >= (1ull << 32) || batch >= (1ull << 31)) return -2;
+  switch (logn) {
+    case 9: return launch_slots_t<9>(cfg, d_prog, d_slots, nslots, ops, d_key_ntt, d_key_inf, T, d_tw, d_ws, d_norms, d_scratch, d_flags, (uint32_t)batch, np_store);
+    case 10: return launch_slots_t<10>(cfg, d_prog, d_slots, nslots, ops, d_key_ntt, d_key_inf, T, d_tw, d_ws, d_norms, d_scratch, d_flags, (uint32_t)batch, np_store);
+    case 11: return launch_slots_t<11>(cfg, d_prog, d_slots, nslots, ops, d_key_ntt, d_key_inf, T, d_tw, d_ws, d_norms, d_scratch, d_flags, (uint32_t)batch, np_store);
+  }
   return -1;
 }
 

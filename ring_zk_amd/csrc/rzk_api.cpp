@@ -49,6 +49,7 @@ struct DevProg {
   SlotTable* d_slots = nullptr;
   uint32_t nslots = 0;
   uint32_t np_store = 0;
+  uint32_t ngroups = 0;   // > 0: row groups (row_group_kernel)
 };
 
 struct Arena {   // grow-only device buffer
@@ -71,6 +72,8 @@ struct rzk_ctx {
   DevTables* dT = nullptr;
   uint32_t* d_tw = nullptr;
   uint32_t* d_row_scratch = nullptr;   // per-wave Garner state of the row kernel (third prime only)
+  uint32_t* d_group_scratch = nullptr; // per-wave Garner state of the row-group kernel (allocated on first use)
+  bool use_groups = true;
   bool small = false;                  // N < 512: schoolbook kernels (rzk_kernels.hip, "small ring degrees")
   uint32_t r2q = 0;                    // 2^64 mod q
   uint32_t* d_key_mont = nullptr;      // small N: key entries as Montgomery-form residues mod q
@@ -412,6 +415,40 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
   if (rc != RZK_OK) return fail(c, rc, "unknown program");
   if (pb.overflow) return fail(c, RZK_E_UNSUPPORTED, "shape exceeds row-program capacity");
   DevProg dp;
+  // Row groups: consecutive rows that are key products over the same operand list are evaluated by one
+  // wavefront (row_group_kernel).  Used when it at least halves the number of tasks.
+  pb.p.ngroups = 0;
+  if (!c->small && c->use_groups) {
+    bool key_only = pb.p.nterms > 0;
+    for (uint32_t t = 0; t < pb.p.nterms; ++t) key_only = key_only && (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_KEY;
+    if (key_only) {
+      const uint32_t gmax = (uint32_t)group_max_for((int)c->logn);
+      uint32_t ng = 0;
+      for (uint32_t r = 0; r < pb.p.nrows;) {
+        uint32_t cnt = 1;
+        const Row& r0 = pb.p.rows[r];
+        while (cnt < gmax && r + cnt < pb.p.nrows) {
+          const Row& rr = pb.p.rows[r + cnt];
+          bool same = rr.nterms == r0.nterms && r0.nterms > 0;
+          for (uint32_t t = 0; same && t < r0.nterms; ++t) {
+            const Term& a = pb.p.terms[r0.term0 + t];
+            const Term& b2 = pb.p.terms[rr.term0 + t];
+            same = a.b_op == b2.b_op && a.b_off == b2.b_off;
+          }
+          if (!same) break;
+          ++cnt;
+        }
+        pb.p.groups[ng].row0 = (uint16_t)r;
+        pb.p.groups[ng].count = (uint16_t)cnt;
+        ++ng;
+        r += cnt;
+      }
+      if (ng * 2 <= pb.p.nrows) {
+        pb.p.ngroups = ng;
+        dp.ngroups = ng;
+      }
+    }
+  }
   HIPCHK(c, hipMalloc((void**)&dp.d, sizeof(Program)));
   HIPCHK(c, hipMemcpyAsync(dp.d, &pb.p, sizeof(Program), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));   // pb.p is a stack object; one-off per (program, shape)
@@ -419,7 +456,7 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
   for (uint32_t t = 0; t < pb.p.nterms; ++t) dp.has_vec = dp.has_vec || (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_VEC;
   // distinct operands of the product terms ("slots"); when rows share them often enough, transform each
   // once per proof (shared-operand path) instead of once per row
-  if (!c->small && c->slot_share_min > 0 && pb.p.nterms > 0) {
+  if (!c->small && c->slot_share_min > 0 && pb.p.nterms > 0 && dp.ngroups == 0) {
     std::vector<SlotTable> stv(1);
     SlotTable& st = stv[0];
     std::memset(&st, 0, sizeof(st));
@@ -505,6 +542,11 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
   int lrc = 0;
   if (c->small) {
     lrc = launch_row_program_small(c->N, cfg_of(c), dp.d, dp.nrows, ops, c->d_key_mont, c->dT, c->r2q, flags, batch);
+  } else if (dp.ngroups) {
+    if (!c->d_group_scratch)
+      HIPCHK(c, hipMalloc((void**)&c->d_group_scratch, group_scratch_words((int)c->logn, c->num_cus) * sizeof(uint32_t)));
+    lrc = launch_row_groups((int)c->logn, cfg_of(c), dp.d, dp.ngroups, ops, c->d_key_ntt, c->d_key_inf, c->dT, c->d_tw,
+                            c->d_group_scratch, flags, batch);
   } else if (dp.d_slots) {
     // shared-operand path; the workspace of stored transforms is bounded, so large batches go in chunks
     const size_t per_item = (size_t)dp.nslots * dp.np_store * c->N * sizeof(uint32_t) + (size_t)dp.nslots * 16;
@@ -673,7 +715,8 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
     return create_fail(RZK_E_HIP, std::string("hipStreamCreate: ") + hipGetErrorString(de));
   }
   c->stream = c->own_stream;
-  if (const char* e = std::getenv("RZK_SLOT_SHARE_MIN")) c->slot_share_min = std::atof(e);   // tuning knob
+  if (const char* e = std::getenv("RZK_SLOT_SHARE_MIN")) c->slot_share_min = std::atof(e);   // tuning knobs
+  if (const char* e = std::getenv("RZK_ROW_GROUPS")) c->use_groups = std::atoi(e) != 0;
   // twiddle tables: 3 primes x {fwd, inv} x kTableLen
   std::vector<uint32_t> all((size_t)2 * kMaxPrimes * kTableLen);
   for (int i = 0; i < kMaxPrimes; ++i) {
@@ -716,6 +759,7 @@ void rzk_ctx_destroy(rzk_ctx* c) {
   if (c->dT) (void)hipFree(c->dT);
   if (c->d_tw) (void)hipFree(c->d_tw);
   if (c->d_row_scratch) (void)hipFree(c->d_row_scratch);
+  if (c->d_group_scratch) (void)hipFree(c->d_group_scratch);
   if (c->d_key_mont) (void)hipFree(c->d_key_mont);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;

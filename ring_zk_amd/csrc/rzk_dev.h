@@ -59,8 +59,16 @@ struct Row {
   uint8_t out_op, mode;
   uint16_t out_off;
 };
+// Row groups: consecutive rows made of key products over the SAME operand list (the n rows of a1 over
+// columns n..k-1, the l rows of a2, ...).  One wavefront evaluates a whole group: every shared operand is
+// transformed once and multiplied into up to kGroupMax accumulators (row_group_kernel).
+constexpr int kGroupMax = 4;
+struct GroupDesc {
+  uint16_t row0, count;
+};
 struct Program {
-  uint32_t nrows, nterms, nadds, pad;
+  uint32_t nrows, nterms, nadds, ngroups;
+  GroupDesc groups[kMaxRows];
   Row rows[kMaxRows];
   Term terms[kMaxTerms];
   AddTerm adds[kMaxAdds];
@@ -103,6 +111,12 @@ int launch_row_program_slots(int logn, const LaunchCfg& cfg, const Program* d_pr
                              const double* d_key_inf, const DevTables* d_T, const uint32_t* d_tw, uint32_t* d_ws,
                              double* d_norms, uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch,
                              uint32_t np_store);
+int launch_row_groups(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t ngroups, const Operands& ops,
+                      const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* d_T, const uint32_t* d_tw,
+                      uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch);
+size_t group_scratch_words(int logn, int num_cus);
+// rows per group; 1 = no grouping (at N = 2048 the accumulators cost too many registers: measured slower)
+inline int group_max_for(int logn) { return logn >= 11 ? 1 : kGroupMax; }
 // words of per-wave global scratch the row kernel needs: (max blocks) * 4 waves * N
 size_t row_scratch_words(int logn, int num_cus);
 int launch_key_transform(int logn, const LaunchCfg& cfg, const int64_t* d_key, uint32_t entries,

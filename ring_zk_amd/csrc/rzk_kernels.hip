@@ -398,6 +398,113 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
   }
 }
 
+// ---- row groups ---------------------------------------------------------------------------------------------
+// One wavefront evaluates a GROUP of up to kGroupMax rows that are key products over the same operand
+// list: each operand is loaded, measured and transformed once per prime and multiplied into one
+// accumulator per row.  For [a1;a2].r with (n,k,l) = (4,9,4) that is 23 transforms per prime instead of 56.
+// The Garner state of every row of the group lives in a per-wave global scratch line (L2 resident).
+#ifndef RZK_GROUP_MIN_WAVES
+#define RZK_GROUP_MIN_WAVES 1
+#endif
+template <int LOGN, int GM>
+__global__ void __launch_bounds__(256, RZK_GROUP_MIN_WAVES)
+row_group_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t* __restrict__ key_ntt,
+                 const double* __restrict__ key_inf, const DevTables* __restrict__ Tp,
+                 const uint32_t* __restrict__ tw_all, uint32_t* __restrict__ scratch, uint8_t* __restrict__ flags,
+                 const uint32_t ntasks) {
+  using G = Geo<LOGN>;
+  constexpr int E = G::E;
+  constexpr int N = G::N;
+  static_assert(GM >= 1 && GM <= kGroupMax, "group size");
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t* lds = smem + wave * G::LDS_WORDS;
+  uint32_t* st = scratch + ((size_t)blockIdx.x * 4 + wave) * (size_t)(2 * kGroupMax) * N;   // [g][A|B][N]
+  const DevTables& T = *Tp;
+  const uint32_t ngroups = prog->ngroups;
+
+  for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
+    const uint32_t b = task / ngroups;
+    const uint32_t gi = task - b * ngroups;
+    const uint32_t bo = ops.group > 1 ? b / ops.group : b;
+    const GroupDesc gd = prog->groups[gi];
+    const uint32_t cnt = gd.count;
+    const Row row0 = prog->rows[gd.row0];
+    const uint32_t nt = row0.nterms;
+    int np = kMaxPrimes;
+    if (nt > 0) {
+      double bound[GM];
+#pragma unroll
+      for (int g = 0; g < GM; ++g) bound[g] = 0.0;
+#pragma unroll 1
+      for (int pi = 0; pi < np; ++pi) {
+        const PrimeConsts pc = T.pc[pi];
+        const uint32_t* __restrict__ twf = tw_all + (size_t)(2 * pi) * kTableLen;
+        const bool first = pi == 0;
+        uint32_t acc[GM][E];
+#pragma unroll
+        for (int g = 0; g < GM; ++g)
+#pragma unroll
+          for (int c = 0; c < E; ++c) acc[g][c] = 0;
+#pragma unroll 1
+        for (uint32_t t = 0; t < nt; ++t) {
+          const Term tm0 = prog->terms[row0.term0 + t];
+          uint32_t x[E];
+          double l1 = 0, linf = 0;
+          uint64_t sumsq = 0;
+          const bool chk = first && (tm0.kind & TERM_CHECK);
+          load_lift<LOGN>(x, operand_ptr(ops, tm0.b_op, tm0.b_off, b, bo, N), lane, pc, first, l1, linf, chk, sumsq);
+          if (chk && sumsq >= ops.norm_limit && lane == 0) flags[bo] = 0;
+          wave_fwd<LOGN>(x, lane, lds, twf, pc);
+#pragma unroll
+          for (int g = 0; g < GM; ++g) {
+            if ((uint32_t)g < cnt) {
+              const Term tg = prog->terms[prog->rows[gd.row0 + g].term0 + t];
+              if (first) bound[g] += key_inf[tg.a_off] * l1;
+              const uint4* __restrict__ kp =
+                  reinterpret_cast<const uint4*>(key_ntt + ((size_t)tg.a_off * kMaxPrimes + pi) * N);
+#pragma unroll
+              for (int q4 = 0; q4 < E / 4; ++q4) {
+                const uint4 kv = kp[q4 * 64 + lane];
+                const uint32_t ks[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                  acc[g][4 * q4 + i] = tg.sign >= 0 ? mac_add(acc[g][4 * q4 + i], x[4 * q4 + i], ks[i], pc)
+                                                    : mac_sub(acc[g][4 * q4 + i], x[4 * q4 + i], ks[i], pc);
+              }
+            }
+          }
+        }
+        if (first) {
+          double mxb = bound[0];
+#pragma unroll
+          for (int g = 1; g < GM; ++g) mxb = bound[g] > mxb ? bound[g] : mxb;
+          np = primes_for(mxb, T);
+        }
+        // one inverse-transform instance in a rolled loop; the row's accumulator is picked with selects so
+        // that the accumulator array keeps static register indices
+#pragma unroll 1
+        for (uint32_t g = 0; g < cnt; ++g) {
+          uint32_t w[E];
+#pragma unroll
+          for (int c = 0; c < E; ++c) {
+            uint32_t v = acc[0][c];
+#pragma unroll
+            for (int gg = 1; gg < GM; ++gg) v = g == (uint32_t)gg ? acc[gg][c] : v;
+            w[c] = v;
+          }
+          inverse_and_fold<LOGN>(pi, np, w, lane, lds, twf + kTableLen, pc, st + (size_t)(2 * g) * N,
+                                 st + (size_t)(2 * g + 1) * N, T);
+        }
+      }
+    }
+#pragma unroll 1
+    for (uint32_t g = 0; g < cnt; ++g)
+      row_epilogue<LOGN>(prog, prog->rows[gd.row0 + g], ops, b, bo, lane, nt > 0, np, st + (size_t)(2 * g) * N, T, flags);
+  }
+}
+
 // ---- shared-operand path ------------------------------------------------------------------------------------
 // Forward pass: one wavefront per (proof, slot) transforms the slot's polynomial for the first `np_store`
 // primes into ws[((b*nslots + s)*np_store + pi)*N ...] (canonical residues, NTT-domain layout) and records
@@ -971,6 +1078,37 @@ int launch_row_program(int logn, const LaunchCfg& cfg, const Program* d_prog, ui
     RZK_ROW_CASE(11)
   }
 #undef RZK_ROW_CASE
+  return -1;
+}
+
+size_t group_scratch_words(int logn, int num_cus) {
+  return (size_t)num_cus * 8 * 4 * (size_t)(2 * kGroupMax) * ((size_t)1 << logn);
+}
+
+template <int LOGN>
+static int launch_groups_t(const LaunchCfg& cfg, const Program* d_prog, const Operands& ops, const uint32_t* d_key_ntt,
+                           const double* d_key_inf, const DevTables* T, const uint32_t* d_tw, uint32_t* d_scratch,
+                           uint8_t* d_flags, uint32_t ntasks) {
+  using G = Geo<LOGN>;
+  constexpr int GM = LOGN >= 11 ? 2 : kGroupMax;   // accumulators per wave (N = 2048 is never grouped by the host)
+  hipLaunchKernelGGL((row_group_kernel<LOGN, GM>), dim3(grid_for(ntasks, cfg.num_cus)), dim3(256),
+                     4 * G::LDS_WORDS * sizeof(uint32_t), (hipStream_t)cfg.stream, d_prog, ops, d_key_ntt, d_key_inf, T,
+                     d_tw, d_scratch, d_flags, ntasks);
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_row_groups(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t ngroups, const Operands& ops,
+                      const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T, const uint32_t* d_tw,
+                      uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch) {
+  if (batch == 0 || ngroups == 0) return 0;
+  if (batch * ngroups >= (1ull << 32)) return -2;
+  const uint32_t ntasks = (uint32_t)(batch * ngroups);
+  switch (logn) {
+    case 9: return launch_groups_t<9>(cfg, d_prog, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
+    case 10: return launch_groups_t<10>(cfg, d_prog, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
+    case 11: return launch_groups_t<11>(cfg, d_prog, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
+  }
   return -1;
 }
 

@@ -360,3 +360,57 @@ def test_fused_norm_predicate_exact_at_the_boundary(torch_mod, N):
     dz = synth.challenge(rng, (2,), N, 36)
     assert ctx.open_verify(z, tt, cz, dz).tolist() == [1, 0]
     assert [int(O.open_verify(P, A, z[i], tt[i], cz[i], dz[i]) == 1) for i in range(2)] == [1, 0]
+
+
+@pytest.mark.parametrize("kind", ["dense", "zero_column", "ones_everywhere"])
+def test_unstructured_keys(torch_mod, kind):
+    """The key loader classifies entries (0 / 1 / general) instead of assuming [I | A']: a fully dense key, a key
+    whose random part has a zero column (that column of r is then never loaded by a product, so the fused norm
+    predicate must fall back to the norm kernel) and a key made only of 0/1 entries must all match the oracle."""
+    N, n, k, l = 512, 2, 5, 2
+    ctx = ctx_for(N, n, k, l)
+    P = _P(ctx)
+    rng = np.random.default_rng({"dense": 1, "zero_column": 2, "ones_everywhere": 3}[kind])
+    if kind == "dense":
+        A = synth.uniform(rng, (n + l, k, N))
+    elif kind == "zero_column":
+        A = synth.key(rng, N, n, k, l)
+        A[:, k - 1, :] = 0                      # last column multiplies nothing
+        A[0, 0, :] = 0                          # and row 0 loses its identity entry
+    else:
+        A = np.zeros((n + l, k, N), dtype=np.int64)
+        A[:, :, 0] = rng.integers(0, 2, (n + l, k))
+    ctx.load_key(A)
+    B = 4
+    x = synth.uniform(rng, (B, l, N))
+    r = synth.small(rng, (B, k, N))
+    r[1, k - 1] = synth.uniform(rng, N)         # breaks the constraint through the never-multiplied column
+    y = synth.gauss(rng, (B, k, N), P.sigma)
+    d = synth.challenge(rng, (B,), N, P.kappa)
+    c, t, ok = ctx.open_commit(x, r, y)
+    z = ctx.open_response(y, r, d)
+    z[2, k - 1, :] = P.verify_bound             # norm violation in the last column
+    acc = ctx.open_verify(z, t, c, d)
+    for b in range(B):
+        c_ref, t_ref, ok_ref = O.open_commit(P, A, x[b], r[b], y[b])
+        assert np.array_equal(c[b], c_ref) and np.array_equal(t[b], t_ref) and bool(ok[b]) == ok_ref
+        assert int(acc[b]) == int(O.open_verify(P, A, z[b], t[b], c[b], d[b]) == 1)
+    assert ok.tolist()[1] == 0 and acc.tolist()[2] == 0
+    v = synth.uniform(rng, (B, k, N))
+    mv = ctx.matvec(2, v)
+    for b in range(B):
+        assert np.array_equal(mv[b], O.mat_dot(A, v[b][:, None, :])[:, 0, :])
+    ctx.load_key(synth.key(rng, N, n, k, l))    # restore a regular key for the cached context
+
+
+def test_cmul_with_more_rows_than_a_program_holds(torch_mod):
+    N = 512
+    ctx = ctx_for(N)
+    rng = np.random.default_rng(50)
+    rows = 50                                    # > kMaxRows (48): rows become batch entries sharing p
+    m = synth.uniform(rng, (2, rows, N))
+    p = synth.uniform(rng, (2, N))
+    out = ctx.cmul(m, p)
+    for b in range(2):
+        for i in (0, 17, 49):
+            assert np.array_equal(out[b, i], O.poly_mul(m[b, i], p[b]))

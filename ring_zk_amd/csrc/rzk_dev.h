@@ -141,6 +141,5 @@ int launch_norm_small(uint32_t N, const LaunchCfg& cfg, const int64_t* v, uint32
                       uint64_t limit_lo, uint8_t* ok, uint64_t B, int and_mode, int shift);
 int launch_eq_small(uint32_t N, const LaunchCfg& cfg, const int64_t* a, const int64_t* b, uint32_t rows,
                     uint8_t* eq, uint64_t B);
-int launch_fill_u8(const LaunchCfg& cfg, uint8_t* p, uint8_t v, uint64_t n);
 
 }  // namespace rzk

@@ -875,12 +875,6 @@ eq_kernel(const int64_t* __restrict__ a, const int64_t* __restrict__ b, uint32_t
   }
 }
 
-__global__ void __launch_bounds__(256) fill_u8_kernel(uint8_t* p, uint8_t v, uint64_t n) {
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-       i += (uint64_t)gridDim.x * blockDim.x)
-    p[i] = v;
-}
-
 // =============================================================================================
 // Small ring degrees (N = 4 .. 256): the reference's own unit / integration tests run at N = 4 and
 // N = 16 (src/mat.rs:241, tests/test.rs:8).  One wavefront still owns one row task, but a transform
@@ -1249,15 +1243,6 @@ int launch_eq(int logn, const LaunchCfg& cfg, const int64_t* a, const int64_t* b
       break;
     default: return -1;
   }
-  RZK_LAUNCH_CHECK();
-  return 0;
-}
-
-int launch_fill_u8(const LaunchCfg& cfg, uint8_t* p, uint8_t v, uint64_t n) {
-  if (n == 0) return 0;
-  uint64_t blocks = (n + 255) / 256;
-  if (blocks > 1024) blocks = 1024;
-  hipLaunchKernelGGL(fill_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)cfg.stream, p, v, n);
   RZK_LAUNCH_CHECK();
   return 0;
 }

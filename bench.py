@@ -279,11 +279,13 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32 residues of three 30-bit primes (int64 coefficients at the boundary)",
+            "dtype": "u32",
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload.capitalize()}Proof cycle, N={N}, (n,k,l)=({n},{k},{l}), kappa=36, "
                             + (f"V={V} summands, " if args.workload == "sum" else "") + f"batch={B} proofs per GPU",
+                "arithmetic": "u32 residues of up to three 30-bit NTT primes, exact CRT to the centred residue mod q; "
+                              "int64 coefficients at the boundary",
                 "challenge": "pre-sampled (host RNG is outside the path)",
                 "parallelism": f"batch split over {world} GPU(s), no data-path collective",
                 "accepted": tot_acc,

@@ -39,7 +39,11 @@ enum ProgId : int {
   PG_SUM_U,           // variant = V
   PG_SUM_W2,          // variant = V
   PG_SUM_V3,          // variant = V
+  PG_DMUL,            // out[i] = d (.) src[i], d sparse (shift-add kernel); variant = rows
 };
+// Variant bit 1 (value 2) of the verifier programs: the products with the challenge d were computed by a
+// PG_DMUL pass (shift-add kernel) and enter the rows as plain additions.
+constexpr uint32_t VAR_CHECK = 1, VAR_DPRE = 2;
 
 struct DevProg {
   Program* d = nullptr;
@@ -50,6 +54,7 @@ struct DevProg {
   uint32_t nslots = 0;
   uint32_t np_store = 0;
   uint32_t ngroups = 0;   // > 0: row groups (row_group_kernel)
+  bool shift = false;     // every product has the sparse challenge as multiplier: shift_row_kernel
 };
 
 struct Arena {   // grow-only device buffer
@@ -74,6 +79,8 @@ struct rzk_ctx {
   uint32_t* d_row_scratch = nullptr;   // per-wave Garner state of the row kernel (third prime only)
   uint32_t* d_group_scratch = nullptr; // per-wave Garner state of the row-group kernel (allocated on first use)
   bool use_groups = true;
+  bool use_shift = true;               // challenge products as signed rotations (shift_row_kernel) instead of transforms
+  bool use_dpre = false;               // verifiers: separate shift-add pass for c1(.)d (measured slower: extra HBM round trip)
   bool small = false;                  // N < 512: schoolbook kernels (rzk_kernels.hip, "small ring degrees")
   uint32_t r2q = 0;                    // 2^64 mod q
   uint32_t* d_key_mont = nullptr;      // small N: key entries as Montgomery-form residues mod q
@@ -148,6 +155,7 @@ int arena_reserve(rzk_ctx* c, Arena& a, size_t bytes) {
 struct PB {
   Program p{};
   bool overflow = false;
+  uint32_t sparse_ops = 0;   // bit i: operand i is a challenge (kappa-sparse, +-1): products with it may use shift-add
   int cur = -1;
   void begin_row(uint8_t out_op, uint32_t out_off, uint8_t mode) {
     if (p.nrows >= (uint32_t)kMaxRows) { overflow = true; return; }
@@ -274,6 +282,7 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
       }
       break;
     case PG_RESPONSE:   // ops: 0 = d, then per triple s: 1+3s = y[k], 2+3s = r[k], 3+3s = z[k]
+      pb.sparse_ops = 1u << 0;
       for (uint32_t s = 0; s < var; ++s)
         for (uint32_t i = 0; i < k; ++i) {      // open.rs:113-115: z = y + r (.) d
           pb.begin_row((uint8_t)(3 + 3 * s), i, MODE_STORE);
@@ -281,13 +290,21 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
           pb.add(+1, (uint8_t)(1 + 3 * s), i);
         }
       break;
-    case PG_A1_RELATION:   // ops: 0 = z[k], 1 = t[n], 2 = c[n+l], 3 = d ; flags &= (a1.z == t + c1(.)d)
+    case PG_DMUL:       // ops: 0 = d, 1 = src[rows], 2 = out[rows]
+      pb.sparse_ops = 1u << 0;
+      for (uint32_t i = 0; i < var; ++i) {
+        pb.begin_row(2, i, MODE_STORE);
+        pb.vec_term(+1, 0, 0, 1, i);
+      }
+      break;
+    case PG_A1_RELATION:   // ops: 0 = z[k], 1 = t[n], 2 = c[n+l], 3 = d, 4 = dc1[n] (VAR_DPRE) ; flags &= (a1.z == t + c1(.)d)
       // c1 = first l rows of c (Commitment::c1_c2 -> split_rows(n), commit.rs:213-218, mat.rs:203-213);
       // Mat::add requires it to have n rows, so n == l is checked by the caller.
       for (uint32_t i = 0; i < n; ++i) {
         pb.begin_row(0, 0, MODE_ZERO);
         key_row(c, pb, +1, i, 0, 0);
-        pb.vec_term(-1, 3, 0, 2, i);
+        if (var & VAR_DPRE) pb.add(-1, 4, i);
+        else pb.vec_term(-1, 3, 0, 2, i);
         pb.add(-1, 1, i);
       }
       if (var & 1) {   // fused check_verify_constraint(z)  (open.rs:167-169)
@@ -402,7 +419,7 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
 
 int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
   const bool needs_key = !(id == PG_POLYMUL || id == PG_CMUL || id == PG_RESPONSE || id == PG_SUM_XP ||
-                           id == PG_SUM_W2);
+                           id == PG_SUM_W2 || id == PG_DMUL);
   if (needs_key && !c->key_loaded) return fail(c, RZK_E_STATE, "commitment key not loaded");
   auto it = c->progs.find({id, var});
   if (it != c->progs.end()) {
@@ -418,7 +435,15 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
   // Row groups: consecutive rows that are key products over the same operand list are evaluated by one
   // wavefront (row_group_kernel).  Used when it at least halves the number of tasks.
   pb.p.ngroups = 0;
-  if (!c->small && c->use_groups) {
+  if (!c->small && c->use_shift && pb.sparse_ops && pb.p.nterms > 0) {
+    bool all = true;
+    for (uint32_t t = 0; t < pb.p.nterms; ++t) {
+      const Term& tm = pb.p.terms[t];
+      all = all && tm.kind == TERM_VEC && ((pb.sparse_ops >> tm.a_op) & 1u);   // no fused checks either
+    }
+    dp.shift = all;
+  }
+  if (!c->small && c->use_groups && !dp.shift) {
     bool key_only = pb.p.nterms > 0;
     for (uint32_t t = 0; t < pb.p.nterms; ++t) key_only = key_only && (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_KEY;
     if (key_only) {
@@ -456,7 +481,7 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
   for (uint32_t t = 0; t < pb.p.nterms; ++t) dp.has_vec = dp.has_vec || (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_VEC;
   // distinct operands of the product terms ("slots"); when rows share them often enough, transform each
   // once per proof (shared-operand path) instead of once per row
-  if (!c->small && c->slot_share_min > 0 && pb.p.nterms > 0 && dp.ngroups == 0) {
+  if (!c->small && c->slot_share_min > 0 && pb.p.nterms > 0 && dp.ngroups == 0 && !dp.shift) {
     std::vector<SlotTable> stv(1);
     SlotTable& st = stv[0];
     std::memset(&st, 0, sizeof(st));
@@ -542,6 +567,8 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
   int lrc = 0;
   if (c->small) {
     lrc = launch_row_program_small(c->N, cfg_of(c), dp.d, dp.nrows, ops, c->d_key_mont, c->dT, c->r2q, flags, batch);
+  } else if (dp.shift) {
+    lrc = launch_shift_rows((int)c->logn, cfg_of(c), dp.d, dp.nrows, ops, c->dT, flags, batch);
   } else if (dp.ngroups) {
     if (!c->d_group_scratch)
       HIPCHK(c, hipMalloc((void**)&c->d_group_scratch, group_scratch_words((int)c->logn, c->num_cus) * sizeof(uint32_t)));
@@ -616,6 +643,9 @@ int run_program_checked(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSp
   if (preset) HIPCHK(c, hipMemsetAsync(flags, 1, nflags, c->stream));
   return run_program(c, id, var | 1, specs, flags, group, batch, lim);
 }
+
+// products with the challenge computed ahead by the shift-add kernel?
+bool dpre(const rzk_ctx* c) { return c->use_dpre && c->use_shift && !c->small; }
 
 bool can_fuse(rzk_ctx* c, int id, uint32_t var, uint64_t bound) {
   DevProg dp;
@@ -717,6 +747,8 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
   c->stream = c->own_stream;
   if (const char* e = std::getenv("RZK_SLOT_SHARE_MIN")) c->slot_share_min = std::atof(e);   // tuning knobs
   if (const char* e = std::getenv("RZK_ROW_GROUPS")) c->use_groups = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RZK_SHIFT")) c->use_shift = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RZK_DPRE")) c->use_dpre = std::atoi(e) != 0;
   // twiddle tables: 3 primes x {fwd, inv} x kTableLen
   std::vector<uint32_t> all((size_t)2 * kMaxPrimes * kTableLen);
   for (int i = 0; i < kMaxPrimes; ++i) {
@@ -971,13 +1003,24 @@ int rzk_open_verify_batch_dev(rzk_ctx* c, const int64_t* z, const int64_t* t, co
                               uint8_t* accept, size_t B) {
   if (!c || !z || !t || !cm || !d || !accept) return RZK_E_ARG;
   if (c->n != c->l) return fail(c, RZK_E_ARG, "c1_c2 split needs n == l (reference panics in Mat::add)");
-  const std::vector<OpSpec> specs = {{z, c->k, 0}, {t, c->n, 0}, {cm, c->n + c->l, 0}, {d, 1, 0}};
+  std::vector<OpSpec> specs = {{z, c->k, 0}, {t, c->n, 0}, {cm, c->n + c->l, 0}, {d, 1, 0}};
+  uint32_t var = 0;
+  int rc;
+  if (dpre(c)) {   // c1 (.) d as kappa signed rotations (open.rs:172), then one addition in the relation rows
+    rc = arena_reserve(c, c->ws, polys(c, B * c->n));
+    if (rc != RZK_OK) return rc;
+    int64_t* dc1 = (int64_t*)c->ws.p;
+    rc = run_program(c, PG_DMUL, c->n, {{d, 1, 0}, {cm, c->n + c->l, 0}, {dc1, c->n, 0}}, nullptr, 1, B);
+    if (rc != RZK_OK) return rc;
+    specs.push_back({dc1, c->n, 0});
+    var = VAR_DPRE;
+  }
   // open.rs:167-169: the norm predicate on z is fused into the rows that load z (one launch per verify)
-  int rc = run_program_checked(c, PG_A1_RELATION, 0, specs, accept, 1, B, B, c->verify_bound);
+  rc = run_program_checked(c, PG_A1_RELATION, var, specs, accept, 1, B, B, c->verify_bound);
   if (rc != RZK_E_UNSUPPORTED) return rc;
   rc = run_norm(c, z, c->k, c->verify_bound, accept, B, 0, 0);
   if (rc != RZK_OK) return rc;
-  return run_program(c, PG_A1_RELATION, 0, specs, accept, 1, B);
+  return run_program(c, PG_A1_RELATION, var, specs, accept, 1, B);
 }
 
 // =================================================================================================

@@ -115,6 +115,9 @@ int launch_row_groups(int logn, const LaunchCfg& cfg, const Program* d_prog, uin
                       const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* d_T, const uint32_t* d_tw,
                       uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch);
 size_t group_scratch_words(int logn, int num_cus);
+// rows whose products all have a sparse multiplier (the challenge) as `a` operand: shift-add kernel, no transforms
+int launch_shift_rows(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows, const Operands& ops,
+                      const DevTables* d_T, uint8_t* d_flags, uint64_t batch);
 // rows per group; 1 = no grouping (at N = 2048 the accumulators cost too many registers: measured slower)
 inline int group_max_for(int logn) { return logn >= 11 ? 1 : kGroupMax; }
 // words of per-wave global scratch the row kernel needs: (max blocks) * 4 waves * N

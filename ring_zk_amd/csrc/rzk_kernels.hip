@@ -398,6 +398,198 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
   }
 }
 
+// =============================================================================================
+// Shift-add row kernel: rows whose products all have a SPARSE multiplier as their `a` operand — the
+// challenge d (kappa coefficients +-1, src/challenge_space.rs:12-33) in z = y + r(.)d and in the d-products
+// of the verifiers.  No transform at all: the wave keeps the extended image of the other operand in LDS
+// (ShiftGeo, rzk_core.h) and adds one rotation per non-zero coefficient of the multiplier; the multiplier's
+// coefficients stay in registers and are walked with ballot / readlane (wave-uniform control flow).
+// Exact for ANY multiplier (cost ~ its number of non-zeros): sums are kept in 32 bits when the multiplier
+// is +-1-valued and |d|_1 |v|_inf < 2^30, in 64 bits (v_mad_i64_i32) below 2^62, and in two 16-bit passes
+// beyond that.
+// =============================================================================================
+template <int LOGN>
+__device__ __forceinline__ void load_pairs(int32_t* v, const int64_t* __restrict__ src, int lane) {
+  using S = ShiftGeo<LOGN>;
+  const int4* __restrict__ p = reinterpret_cast<const int4*>(src);
+#pragma unroll
+  for (int g = 0; g < S::G; ++g) {
+    const int4 t = p[g * 64 + lane];   // coefficients g*128 + 2*lane, +1 (low words of two int64)
+    v[2 * g] = t.x;
+    v[2 * g + 1] = t.z;
+  }
+}
+
+// walk the non-zero coefficients of the multiplier (registers a[], lane-distributed) and add the rotations
+// into the output pairs G0 .. G0+GN-1 of every lane
+template <int LOGN, typename T, bool PM, int G0, int GN>
+__device__ __forceinline__ void shift_scan(T* acc, const int32_t* a, int lane, const int32_t* ext) {
+  using S = ShiftGeo<LOGN>;
+#pragma unroll
+  for (int i = 0; i < S::E; ++i) {
+    uint64_t mask = __ballot(a[i] != 0);
+    while (mask) {
+      const int l = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const int32_t coef = __builtin_amdgcn_readlane(a[i], l);
+      const int s = (i >> 1) * 128 + 2 * l + (i & 1);
+      if constexpr (PM) shift_accum_pm<LOGN>(reinterpret_cast<int32_t*>(acc), lane, s, coef < 0, ext);
+      else shift_accum<LOGN, T, G0, GN>(acc, lane, s, coef, ext);
+    }
+  }
+}
+
+#ifndef RZK_SHIFT_MIN_WAVES
+#define RZK_SHIFT_MIN_WAVES 1
+#endif
+template <int LOGN>
+struct ShiftCfg {   // waves per workgroup: one wave's image is 8 * N bytes of LDS, 32 KiB per workgroup at most
+  static constexpr int WPB = LOGN <= 10 ? 4 : 2;
+};
+
+template <int LOGN>
+__global__ void __launch_bounds__(64 * ShiftCfg<LOGN>::WPB, RZK_SHIFT_MIN_WAVES)
+shift_row_kernel(const Program* __restrict__ prog, const Operands ops, const DevTables* __restrict__ Tp,
+                 uint8_t* __restrict__ flags, const uint32_t ntasks) {
+  using S = ShiftGeo<LOGN>;
+  constexpr int E = S::E;
+  constexpr int N = S::N;
+  constexpr int WPB = ShiftCfg<LOGN>::WPB;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int32_t* slab = reinterpret_cast<int32_t*>(smem) + wave * S::WORDS;
+  const DevTables& T = *Tp;
+  const uint32_t q = T.crt.q;
+  const uint32_t nrows = prog->nrows;
+
+  for (uint32_t task = blockIdx.x * WPB + wave; task < ntasks; task += gridDim.x * WPB) {
+    const uint32_t b = task / nrows;
+    const uint32_t rowi = task - b * nrows;
+    const uint32_t bo = ops.group > 1 ? b / ops.group : b;
+    const Row row = prog->rows[rowi];
+    uint32_t res[E];
+#pragma unroll
+    for (int i = 0; i < E; ++i) res[i] = 0;
+    // the first addition is fetched ahead of the rotations so that its latency is hidden behind them
+    int32_t av0[E];
+    AddTerm ad0{};
+    if (row.nadds > 0) {
+      ad0 = prog->adds[row.add0];
+      load_pairs<LOGN>(av0, operand_ptr(ops, ad0.op & ADD_OP_MASK, ad0.off, b, bo, N), lane);
+    }
+
+#pragma unroll 1
+    for (uint32_t t = 0; t < row.nterms; ++t) {
+      const Term tm = prog->terms[row.term0 + t];
+      int32_t a[E], v[E];
+      load_pairs<LOGN>(a, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), lane);
+      load_pairs<LOGN>(v, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane);
+      uint64_t suma = 0;
+      uint32_t maxa = 0, maxv = 0;
+#pragma unroll
+      for (int i = 0; i < E; ++i) {
+        const uint32_t aa = (uint32_t)(a[i] < 0 ? -a[i] : a[i]);
+        const uint32_t vv = (uint32_t)(v[i] < 0 ? -v[i] : v[i]);
+        suma += aa;
+        maxa = aa > maxa ? aa : maxa;
+        maxv = vv > maxv ? vv : maxv;
+      }
+      const double l1a = (double)wave_sum_u64(suma);
+      const uint32_t ainf = wave_max_u32(maxa);
+      const double bound = l1a * (double)wave_max_u32(maxv);   // |exact product|_inf <= bound
+      const int mode = __builtin_amdgcn_readfirstlane(
+          (ainf <= 1u && bound < 1073741824.0) ? 0 : (bound < 4.0e18 ? 1 : 2));   // 2^30 ; < 2^62
+      uint32_t tr[E];
+      if (mode == 0) {
+        wave_sync();   // earlier reads of the images are done before they are overwritten
+        shift_fill<LOGN>(v, lane, slab, SHIFT_WHOLE);
+        wave_sync();
+        int32_t acc[E];
+#pragma unroll
+        for (int i = 0; i < E; ++i) acc[i] = 0;
+        shift_scan<LOGN, int32_t, true, 0, S::G>(acc, a, lane, slab);
+#pragma unroll
+        for (int i = 0; i < E; ++i) tr[i] = zq_from_centered(acc[i], q);
+      } else {
+#pragma unroll 1
+        for (int pass = 0; pass < mode; ++pass) {
+          wave_sync();
+          shift_fill<LOGN>(v, lane, slab, mode == 1 ? SHIFT_WHOLE : (pass == 0 ? SHIFT_LOW16 : SHIFT_HIGH16));
+          wave_sync();
+          // 64-bit sums, half of the outputs at a time (register budget); high halves carry the weight 2^16
+          {
+            int64_t acc[E / 2];
+#pragma unroll
+            for (int i = 0; i < E / 2; ++i) acc[i] = 0;
+            shift_scan<LOGN, int64_t, false, 0, S::G / 2>(acc, a, lane, slab);
+#pragma unroll
+            for (int i = 0; i < E / 2; ++i) {
+              const uint32_t u = zq_from_i64(acc[i], T.crt);
+              tr[i] = pass == 0 ? u : addq(tr[i], montq_u(u, T.crt.r48q, T.crt), q);
+            }
+          }
+          {
+            int64_t acc[E / 2];
+#pragma unroll
+            for (int i = 0; i < E / 2; ++i) acc[i] = 0;
+            shift_scan<LOGN, int64_t, false, S::G / 2, S::G / 2>(acc, a, lane, slab);
+#pragma unroll
+            for (int i = 0; i < E / 2; ++i) {
+              const uint32_t u = zq_from_i64(acc[i], T.crt);
+              tr[E / 2 + i] = pass == 0 ? u : addq(tr[E / 2 + i], montq_u(u, T.crt.r48q, T.crt), q);
+            }
+          }
+        }
+      }
+      if (tm.sign >= 0) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) res[i] = addq(res[i], tr[i], q);
+      } else {
+#pragma unroll
+        for (int i = 0; i < E; ++i) res[i] = subq(res[i], tr[i], q);
+      }
+    }
+
+    if (row.nadds > 0) {
+      if (ad0.sign >= 0) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) res[i] = addq(res[i], zq_from_centered(av0[i], q), q);
+      } else {
+#pragma unroll
+        for (int i = 0; i < E; ++i) res[i] = subq(res[i], zq_from_centered(av0[i], q), q);
+      }
+    }
+#pragma unroll 1
+    for (uint32_t ai = 1; ai < row.nadds; ++ai) {
+      const AddTerm ad = prog->adds[row.add0 + ai];
+      int32_t av[E];
+      load_pairs<LOGN>(av, operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, N), lane);
+      if (ad.sign >= 0) {
+#pragma unroll
+        for (int i = 0; i < E; ++i) res[i] = addq(res[i], zq_from_centered(av[i], q), q);
+      } else {
+#pragma unroll
+        for (int i = 0; i < E; ++i) res[i] = subq(res[i], zq_from_centered(av[i], q), q);
+      }
+    }
+    if (row.mode == MODE_STORE) {
+      int4* __restrict__ dst = reinterpret_cast<int4*>(const_cast<int64_t*>(operand_ptr(ops, row.out_op, row.out_off, b, bo, N)));
+#pragma unroll
+      for (int g = 0; g < S::G; ++g) {
+        const int64_t c0 = center_from_zq(res[2 * g], T.crt), c1 = center_from_zq(res[2 * g + 1], T.crt);
+        dst[g * 64 + lane] = make_int4((int32_t)c0, (int32_t)(c0 >> 32), (int32_t)c1, (int32_t)(c1 >> 32));
+      }
+    } else {
+      int nz = 0;
+#pragma unroll
+      for (int i = 0; i < E; ++i) nz |= (res[i] != 0);
+      if (__any(nz) && lane == 0) flags[bo] = 0;
+    }
+  }
+}
+
+
 // ---- row groups ---------------------------------------------------------------------------------------------
 // One wavefront evaluates a GROUP of up to kGroupMax rows that are key products over the same operand
 // list: each operand is loaded, measured and transformed once per prime and multiplied into one
@@ -1072,6 +1264,32 @@ int launch_row_program(int logn, const LaunchCfg& cfg, const Program* d_prog, ui
     RZK_ROW_CASE(11)
   }
 #undef RZK_ROW_CASE
+  return -1;
+}
+
+template <int LOGN>
+static int launch_shift_t(const LaunchCfg& cfg, const Program* d_prog, const Operands& ops, const DevTables* T,
+                          uint8_t* d_flags, uint32_t ntasks) {
+  using S = ShiftGeo<LOGN>;
+  constexpr int WPB = ShiftCfg<LOGN>::WPB;
+  const size_t lds = (size_t)WPB * S::WORDS * sizeof(uint32_t);
+  const unsigned grid = grid_for(ntasks, cfg.num_cus, WPB, 16);
+  hipLaunchKernelGGL((shift_row_kernel<LOGN>), dim3(grid), dim3(64 * WPB), lds, (hipStream_t)cfg.stream, d_prog, ops,
+                     T, d_flags, ntasks);
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_shift_rows(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows, const Operands& ops,
+                      const DevTables* T, uint8_t* d_flags, uint64_t batch) {
+  if (batch == 0 || nrows == 0) return 0;
+  if (batch * nrows >= (1ull << 32)) return -2;
+  const uint32_t ntasks = (uint32_t)(batch * nrows);
+  switch (logn) {
+    case 9: return launch_shift_t<9>(cfg, d_prog, ops, T, d_flags, ntasks);
+    case 10: return launch_shift_t<10>(cfg, d_prog, ops, T, d_flags, ntasks);
+    case 11: return launch_shift_t<11>(cfg, d_prog, ops, T, d_flags, ntasks);
+  }
   return -1;
 }
 

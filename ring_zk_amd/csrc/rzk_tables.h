@@ -114,6 +114,8 @@ inline bool make_crt_consts(uint64_t q, CrtConsts& C) {
     for (int i = 0; i < 4; ++i) C.hmod[np][i] = i < kMaxPrimes ? (uint32_t)(H % kPrimes[i]) : 0;
     C.hmodq[np] = (uint32_t)(H % q);
   }
+  C.r2q = (uint32_t)((((u128)1) << 64) % q);
+  C.r48q = (uint32_t)((((u128)1) << 48) % q);
   return true;
 }
 

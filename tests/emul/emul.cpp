@@ -116,9 +116,57 @@ int polymul(int np, uint64_t q, const int64_t* a, const int64_t* b, int64_t* out
   return 0;
 }
 
+// out = d * v in Z_q[X]/(X^N+1), centred, by the shift-add scheme of the challenge products (ShiftGeo):
+// mode 0 = 32-bit sums of +-1 rotations, 1 = 64-bit sums, 2 = two 16-bit passes.
+template <int LOGN>
+int shift_product(int mode, uint64_t q, const int64_t* d, const int64_t* v, int64_t* out) {
+  using S = ShiftGeo<LOGN>;
+  CrtConsts C;
+  if (!host::make_crt_consts(q, C)) return -1;
+  static int32_t slab[S::WORDS];
+  static int32_t vr[64][S::E];
+  static uint32_t tr[64][S::E];
+  for (int l = 0; l < 64; ++l)
+    for (int i = 0; i < S::E; ++i) vr[l][i] = (int32_t)v[S::j(l, i)];
+  const int passes = mode == 2 ? 2 : 1;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int part = mode == 2 ? (pass == 0 ? SHIFT_LOW16 : SHIFT_HIGH16) : SHIFT_WHOLE;
+    for (int l = 0; l < 64; ++l) shift_fill<LOGN>(vr[l], l, slab, part);
+    for (int l = 0; l < 64; ++l) {
+      int32_t a32[S::E] = {0};
+      int64_t a64[S::E] = {0};
+      for (int s = 0; s < S::N; ++s) {
+        const int32_t coef = (int32_t)d[s];
+        if (coef == 0) continue;
+        if (mode == 0) {
+          if (coef != 1 && coef != -1) return -3;
+          shift_accum_pm<LOGN>(a32, l, s, coef < 0, slab);
+        } else {
+          shift_accum<LOGN, int64_t>(a64, l, s, coef, slab);
+        }
+      }
+      for (int i = 0; i < S::E; ++i) {
+        const uint32_t u = mode == 0 ? zq_from_centered(a32[i], C.q) : zq_from_i64(a64[i], C);
+        tr[l][i] = pass == 0 ? u : addq(tr[l][i], montq_u(u, C.r48q, C), C.q);
+      }
+    }
+  }
+  for (int l = 0; l < 64; ++l)
+    for (int i = 0; i < S::E; ++i) out[S::j(l, i)] = center_from_zq(tr[l][i], C);
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
+int emul_shift_product(int logn, int mode, uint64_t q, const int64_t* d, const int64_t* v, int64_t* out) {
+  switch (logn) {
+    case 9: return shift_product<9>(mode, q, d, v, out);
+    case 10: return shift_product<10>(mode, q, d, v, out);
+    case 11: return shift_product<11>(mode, q, d, v, out);
+  }
+  return -1;
+}
 int emul_ntt_fwd(int logn, int pi, const uint32_t* in, uint32_t* out_std, uint32_t* out_mem) {
   switch (logn) {
     case 9: return ntt_fwd<9>(pi, in, out_std, out_mem);

@@ -112,3 +112,33 @@ def test_emulated_polymul_fewer_primes(emul, logn):
     b[N - 1] = 7
     b[0] = 3
     assert np.array_equal(_polymul(emul, logn, 1, a, b), O.poly_mul(a, b))
+
+
+@pytest.mark.parametrize("logn", [9, 10, 11])
+def test_emulated_shift_product(emul, logn):
+    """Challenge products as signed negacyclic rotations (ShiftGeo in rzk_core.h) in all three sum widths."""
+    N = 1 << logn
+    rng = np.random.default_rng(500 + logn)
+
+    def run(mode, d, v):
+        out = np.empty(N, dtype=np.int64)
+        d = np.ascontiguousarray(d, dtype=np.int64)
+        v = np.ascontiguousarray(v, dtype=np.int64)
+        assert emul.emul_shift_product(logn, mode, C.c_uint64(Q), _i64p(d), _i64p(v), _i64p(out)) == 0
+        return out
+
+    d = np.zeros(N, dtype=np.int64)
+    pos = rng.choice(N, 36, replace=False)
+    d[pos] = rng.choice([-1, 1], 36)
+    d[0], d[1], d[N - 1], d[N - 2] = 1, -1, -1, 1            # both parities at both ends
+    r = rng.integers(-1, 2, N, dtype=np.int64)
+    assert np.array_equal(run(0, d, r), O.poly_mul(d, r))
+    c1 = rng.integers(-HALF, HALF + 1, N, dtype=np.int64)     # full-range commitment row
+    c1[:2] = [HALF, -HALF]
+    for mode in (1, 2):
+        assert np.array_equal(run(mode, d, c1), O.poly_mul(d, c1))
+    dd = rng.integers(-HALF, HALF + 1, N, dtype=np.int64)     # dense full-range multiplier: sums up to 2^72
+    dd[:2] = [-HALF, HALF]
+    assert np.array_equal(run(2, dd, c1), O.poly_mul(dd, c1))
+    small = rng.integers(-1000, 1001, N, dtype=np.int64)
+    assert np.array_equal(run(1, small, c1), O.poly_mul(small, c1))

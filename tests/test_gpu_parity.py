@@ -414,3 +414,49 @@ def test_cmul_with_more_rows_than_a_program_holds(torch_mod):
     for b in range(2):
         for i in (0, 17, 49):
             assert np.array_equal(out[b, i], O.poly_mul(m[b, i], p[b]))
+
+
+# ---- challenge products (shift-add kernel): every accumulation width, any multiplier ------------------------
+@pytest.mark.parametrize("N", [512, 1024, 2048])
+def test_challenge_products_any_multiplier(torch_mod, N):
+    """z = y + r (.) d and a1.z == t + c1 (.) d with multipliers that are NOT kappa-sparse +-1: the
+    shift-add path must stay exact (32-bit sums, 64-bit sums, two 16-bit passes), as the reference is
+    for any polynomial d (src/prove/open.rs:113-115, 172)."""
+    n, k, l = 1, 3, 1
+    ctx = ctx_for(N, n, k, l)
+    P = _P(ctx)
+    rng = np.random.default_rng(900 + N)
+    A = synth.key(rng, N, n, k, l)
+    ctx.load_key(A)
+    B = 6
+    d = synth.challenge(rng, (B,), N, P.kappa)
+    d[0, :] = 0                                                 # zero multiplier
+    d[1] = synth.challenge(rng, (1,), N, P.kappa)[0] * 3        # sparse, coefficients +-3 -> 64-bit sums
+    d[2] = synth.uniform(rng, (N,))                             # dense full range -> 16-bit passes
+    d[3, :] = 0
+    d[3, [0, 1, N - 2, N - 1]] = [1, -1, 1, -1]                 # rotations by 0, 1, N-2, N-1
+    d[4] = rng.integers(-1, 2, N)                               # dense ternary
+    y = synth.gauss(rng, (B, k, N), P.sigma)
+    r = synth.small(rng, (B, k, N))
+    r[2] = synth.uniform(rng, (k, N))                           # full-range r times full-range d
+    r[5] = synth.uniform(rng, (k, N))                           # full-range r times a real challenge
+    r[2, 0, :2] = [HALF, -HALF]
+    d[2, :2] = [-HALF, HALF]
+    z = ctx.open_response(y, r, d)
+    for b in range(B):
+        assert np.array_equal(z[b], O.open_response(P, y[b], r[b], d[b])), b
+    # verification equation with the same multipliers; t is chosen so that every proof satisfies it
+    zs = synth.gauss(rng, (B, k, N), P.sigma // 4)
+    c = synth.uniform(rng, (B, n + l, N))
+    t = np.empty((B, n, N), dtype=np.int64)
+    for b in range(B):
+        lhs = O.mat_dot(A[:n], zs[b][:, None, :])
+        t[b] = O.mat_sub(lhs, O.mat_cmul(c[b, :n][:, None, :], d[b]))[:, 0, :]
+    acc = ctx.open_verify(zs, t, c, d)
+    assert acc.tolist() == [1] * B
+    t[4, 0, 7] = O.center(int(t[4, 0, 7]) + 1)
+    t[2, 0, N - 1] = O.center(int(t[2, 0, N - 1]) - 1)
+    acc = ctx.open_verify(zs, t, c, d)
+    assert acc.tolist() == [1, 1, 0, 1, 0, 1]
+    for b in range(B):
+        assert int(acc[b]) == int(O.open_verify(P, A, zs[b], t[b], c[b], d[b]) == 1)

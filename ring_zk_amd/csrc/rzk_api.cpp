@@ -39,11 +39,7 @@ enum ProgId : int {
   PG_SUM_U,           // variant = V
   PG_SUM_W2,          // variant = V
   PG_SUM_V3,          // variant = V
-  PG_DMUL,            // out[i] = d (.) src[i], d sparse (shift-add kernel); variant = rows
 };
-// Variant bit 1 (value 2) of the verifier programs: the products with the challenge d were computed by a
-// PG_DMUL pass (shift-add kernel) and enter the rows as plain additions.
-constexpr uint32_t VAR_CHECK = 1, VAR_DPRE = 2;
 
 struct DevProg {
   Program* d = nullptr;
@@ -55,6 +51,7 @@ struct DevProg {
   uint32_t np_store = 0;
   uint32_t ngroups = 0;   // > 0: row groups (row_group_kernel)
   bool shift = false;     // every product has the sparse challenge as multiplier: shift_row_kernel
+  bool has_shift = false; // some rows end with challenge products evaluated by rotations inside row_kernel
 };
 
 struct Arena {   // grow-only device buffer
@@ -80,7 +77,6 @@ struct rzk_ctx {
   uint32_t* d_group_scratch = nullptr; // per-wave Garner state of the row-group kernel (allocated on first use)
   bool use_groups = true;
   bool use_shift = true;               // challenge products as signed rotations (shift_row_kernel) instead of transforms
-  bool use_dpre = false;               // verifiers: separate shift-add pass for c1(.)d (measured slower: extra HBM round trip)
   bool small = false;                  // N < 512: schoolbook kernels (rzk_kernels.hip, "small ring degrees")
   uint32_t r2q = 0;                    // 2^64 mod q
   uint32_t* d_key_mont = nullptr;      // small N: key entries as Montgomery-form residues mod q
@@ -164,13 +160,15 @@ struct PB {
     r.term0 = (uint16_t)p.nterms;
     r.add0 = (uint16_t)p.nadds;
     r.nterms = r.nadds = 0;
+    r.nshift = r.pad = 0;
     r.out_op = out_op;
     r.out_off = (uint16_t)out_off;
     r.mode = mode;
     if (out_off > 0xffff) overflow = true;
   }
+  // total terms of the program so far (transform terms and shift terms share Program::terms)
   void key_term(int sign, uint32_t entry, uint8_t vop, uint32_t voff) {
-    if (cur < 0 || p.nterms >= (uint32_t)kMaxTerms || entry > 0xffff || voff > 0xffff) { overflow = true; return; }
+    if (cur < 0 || p.nterms >= (uint32_t)kMaxTerms || entry > 0xffff || voff > 0xffff || p.rows[cur].nshift) { overflow = true; return; }
     Term& t = p.terms[p.nterms++];
     t.kind = TERM_KEY;
     t.sign = (int8_t)sign;
@@ -181,7 +179,7 @@ struct PB {
     p.rows[cur].nterms++;
   }
   void vec_term(int sign, uint8_t aop, uint32_t aoff, uint8_t bop, uint32_t boff) {
-    if (cur < 0 || p.nterms >= (uint32_t)kMaxTerms || aoff > 0xffff || boff > 0xffff) { overflow = true; return; }
+    if (cur < 0 || p.nterms >= (uint32_t)kMaxTerms || aoff > 0xffff || boff > 0xffff || p.rows[cur].nshift) { overflow = true; return; }
     Term& t = p.terms[p.nterms++];
     t.kind = TERM_VEC;
     t.sign = (int8_t)sign;
@@ -190,6 +188,24 @@ struct PB {
     t.b_op = bop;
     t.b_off = (uint16_t)boff;
     p.rows[cur].nterms++;
+  }
+  // sign * (aop,aoff) (.) (bop,boff) with a sparse `a` (the challenge), evaluated as signed rotations inside the
+  // row kernel; such terms close a row's term list (stored behind its transform terms)
+  void shift_term(int sign, uint8_t aop, uint32_t aoff, uint8_t bop, uint32_t boff) {
+    if (cur < 0 || p.nterms >= (uint32_t)kMaxTerms || aoff > 0xffff || boff > 0xffff) { overflow = true; return; }
+    Term& t = p.terms[p.nterms++];
+    t.kind = TERM_SHIFT;
+    t.sign = (int8_t)sign;
+    t.a_op = aop;
+    t.a_off = (uint16_t)aoff;
+    t.b_op = bop;
+    t.b_off = (uint16_t)boff;
+    p.rows[cur].nshift++;
+  }
+  // product with the challenge: rotations when enabled, transform product otherwise
+  void challenge_term(bool rotate, int sign, uint8_t dop, uint8_t bop, uint32_t boff) {
+    if (rotate) shift_term(sign, dop, 0, bop, boff);
+    else vec_term(sign, dop, 0, bop, boff);
   }
   void add(int sign, uint8_t op, uint32_t off) {
     if (cur < 0 || p.nadds >= (uint32_t)kMaxAdds || off > 0xffff) { overflow = true; return; }
@@ -242,8 +258,14 @@ void key_row(rzk_ctx* c, PB& pb, int sign, uint32_t krow, uint8_t vop, uint32_t 
   }
 }
 
+// Challenge products as signed rotations (shift-add) instead of transforms: N = 512 and 1024.  At N = 2048 a
+// lane holds 32 outputs, the rotation kernels need > 200 VGPRs (one or two waves per SIMD) and measured slower
+// than the transform path.
+bool shift_ok(const rzk_ctx* c) { return c->use_shift && !c->small && c->logn <= 10; }
+
 int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
   const uint32_t n = c->n, k = c->k, l = c->l;
+  const bool rot = shift_ok(c);   // challenge products inside mixed rows as rotations
   switch (id) {
     case PG_MATVEC: {   // ops: 0 = v[k], 1 = addend[rows], 2 = out[rows]
       const uint32_t which = var >> 1;
@@ -290,21 +312,13 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
           pb.add(+1, (uint8_t)(1 + 3 * s), i);
         }
       break;
-    case PG_DMUL:       // ops: 0 = d, 1 = src[rows], 2 = out[rows]
-      pb.sparse_ops = 1u << 0;
-      for (uint32_t i = 0; i < var; ++i) {
-        pb.begin_row(2, i, MODE_STORE);
-        pb.vec_term(+1, 0, 0, 1, i);
-      }
-      break;
-    case PG_A1_RELATION:   // ops: 0 = z[k], 1 = t[n], 2 = c[n+l], 3 = d, 4 = dc1[n] (VAR_DPRE) ; flags &= (a1.z == t + c1(.)d)
+    case PG_A1_RELATION:   // ops: 0 = z[k], 1 = t[n], 2 = c[n+l], 3 = d ; flags &= (a1.z == t + c1(.)d)
       // c1 = first l rows of c (Commitment::c1_c2 -> split_rows(n), commit.rs:213-218, mat.rs:203-213);
       // Mat::add requires it to have n rows, so n == l is checked by the caller.
       for (uint32_t i = 0; i < n; ++i) {
         pb.begin_row(0, 0, MODE_ZERO);
         key_row(c, pb, +1, i, 0, 0);
-        if (var & VAR_DPRE) pb.add(-1, 4, i);
-        else pb.vec_term(-1, 3, 0, 2, i);
+        pb.challenge_term(rot, -1, 3, 2, i);
         pb.add(-1, 1, i);
       }
       if (var & 1) {   // fused check_verify_constraint(z)  (open.rs:167-169)
@@ -350,13 +364,13 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
       for (uint32_t i = 0; i < n; ++i) {       // linear.rs:225-229
         pb.begin_row(0, 0, MODE_ZERO);
         key_row(c, pb, +1, i, 0, 0);
-        pb.vec_term(-1, 6, 0, 4, i);
+        pb.challenge_term(rot, -1, 6, 4, i);
         pb.add(-1, 2, i);
       }
       for (uint32_t i = 0; i < n; ++i) {       // linear.rs:231-235
         pb.begin_row(0, 0, MODE_ZERO);
         key_row(c, pb, +1, i, 1, 0);
-        pb.vec_term(-1, 6, 0, 5, i);
+        pb.challenge_term(rot, -1, 6, 5, i);
         pb.add(-1, 3, i);
       }
       for (uint32_t i = 0; i < l; ++i) {       // a2.z (linear.rs:238-241), reduced before (.)g
@@ -379,7 +393,7 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
         pb.begin_row(0, 0, MODE_ZERO);
         pb.vec_term(+1, 0, i, 2, 0);
         key_row(c, pb, -1, n + i, 4, 0);
-        pb.vec_term(-1, 3, 0, 1, i);
+        pb.challenge_term(rot, -1, 3, 1, i);
         pb.add(-1, 5, i);
       }
       break;
@@ -408,7 +422,7 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
         pb.begin_row(0, 0, MODE_ZERO);
         for (uint32_t i = 0; i < var; ++i) pb.vec_term(+1, 0, i * l + j, 1, i);
         key_row(c, pb, -1, n + j, 2, 0);
-        pb.vec_term(-1, 4, 0, 3, j);
+        pb.challenge_term(rot, -1, 4, 3, j);
         pb.add(-1, 5, j);
       }
       break;
@@ -419,7 +433,7 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
 
 int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
   const bool needs_key = !(id == PG_POLYMUL || id == PG_CMUL || id == PG_RESPONSE || id == PG_SUM_XP ||
-                           id == PG_SUM_W2 || id == PG_DMUL);
+                           id == PG_SUM_W2);
   if (needs_key && !c->key_loaded) return fail(c, RZK_E_STATE, "commitment key not loaded");
   auto it = c->progs.find({id, var});
   if (it != c->progs.end()) {
@@ -435,7 +449,7 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
   // Row groups: consecutive rows that are key products over the same operand list are evaluated by one
   // wavefront (row_group_kernel).  Used when it at least halves the number of tasks.
   pb.p.ngroups = 0;
-  if (!c->small && c->use_shift && pb.sparse_ops && pb.p.nterms > 0) {
+  if (shift_ok(c) && pb.sparse_ops && pb.p.nterms > 0) {
     bool all = true;
     for (uint32_t t = 0; t < pb.p.nterms; ++t) {
       const Term& tm = pb.p.terms[t];
@@ -443,6 +457,7 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
     }
     dp.shift = all;
   }
+  for (uint32_t r = 0; r < pb.p.nrows; ++r) dp.has_shift = dp.has_shift || pb.p.rows[r].nshift > 0;
   if (!c->small && c->use_groups && !dp.shift) {
     bool key_only = pb.p.nterms > 0;
     for (uint32_t t = 0; t < pb.p.nterms; ++t) key_only = key_only && (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_KEY;
@@ -481,7 +496,7 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
   for (uint32_t t = 0; t < pb.p.nterms; ++t) dp.has_vec = dp.has_vec || (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_VEC;
   // distinct operands of the product terms ("slots"); when rows share them often enough, transform each
   // once per proof (shared-operand path) instead of once per row
-  if (!c->small && c->slot_share_min > 0 && pb.p.nterms > 0 && dp.ngroups == 0 && !dp.shift) {
+  if (!c->small && c->slot_share_min > 0 && pb.p.nterms > 0 && dp.ngroups == 0 && !dp.shift && !dp.has_shift) {
     std::vector<SlotTable> stv(1);
     SlotTable& st = stv[0];
     std::memset(&st, 0, sizeof(st));
@@ -600,8 +615,8 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
                                      flags ? flags + b0 / grp : nullptr, nb, dp.np_store);
     }
   } else {
-    lrc = launch_row_program((int)c->logn, cfg_of(c), dp.d, dp.nrows, dp.has_vec, ops, c->d_key_ntt, c->d_key_inf,
-                             c->dT, c->d_tw, c->d_row_scratch, flags, batch);
+    lrc = launch_row_program((int)c->logn, cfg_of(c), dp.d, dp.nrows, dp.has_vec, dp.has_shift, ops, c->d_key_ntt,
+                             c->d_key_inf, c->dT, c->d_tw, c->d_row_scratch, flags, batch);
   }
   if (lrc == -2) return fail(c, RZK_E_UNSUPPORTED, "batch * rows must stay below 2^32");
   if (lrc != 0) {
@@ -640,12 +655,12 @@ int run_program_checked(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSp
   DevProg dp;
   int rc = get_program(c, id, var | 1, dp);
   if (rc != RZK_OK) return rc;
-  if (preset) HIPCHK(c, hipMemsetAsync(flags, 1, nflags, c->stream));
+  if (preset) {
+    rc = check_launch(c, launch_fill_u8(cfg_of(c), flags, 1, nflags), "flag preset");
+    if (rc != RZK_OK) return rc;
+  }
   return run_program(c, id, var | 1, specs, flags, group, batch, lim);
 }
-
-// products with the challenge computed ahead by the shift-add kernel?
-bool dpre(const rzk_ctx* c) { return c->use_dpre && c->use_shift && !c->small; }
 
 bool can_fuse(rzk_ctx* c, int id, uint32_t var, uint64_t bound) {
   DevProg dp;
@@ -748,7 +763,7 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
   if (const char* e = std::getenv("RZK_SLOT_SHARE_MIN")) c->slot_share_min = std::atof(e);   // tuning knobs
   if (const char* e = std::getenv("RZK_ROW_GROUPS")) c->use_groups = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_SHIFT")) c->use_shift = std::atoi(e) != 0;
-  if (const char* e = std::getenv("RZK_DPRE")) c->use_dpre = std::atoi(e) != 0;
+
   // twiddle tables: 3 primes x {fwd, inv} x kTableLen
   std::vector<uint32_t> all((size_t)2 * kMaxPrimes * kTableLen);
   for (int i = 0; i < kMaxPrimes; ++i) {
@@ -1003,24 +1018,13 @@ int rzk_open_verify_batch_dev(rzk_ctx* c, const int64_t* z, const int64_t* t, co
                               uint8_t* accept, size_t B) {
   if (!c || !z || !t || !cm || !d || !accept) return RZK_E_ARG;
   if (c->n != c->l) return fail(c, RZK_E_ARG, "c1_c2 split needs n == l (reference panics in Mat::add)");
-  std::vector<OpSpec> specs = {{z, c->k, 0}, {t, c->n, 0}, {cm, c->n + c->l, 0}, {d, 1, 0}};
-  uint32_t var = 0;
-  int rc;
-  if (dpre(c)) {   // c1 (.) d as kappa signed rotations (open.rs:172), then one addition in the relation rows
-    rc = arena_reserve(c, c->ws, polys(c, B * c->n));
-    if (rc != RZK_OK) return rc;
-    int64_t* dc1 = (int64_t*)c->ws.p;
-    rc = run_program(c, PG_DMUL, c->n, {{d, 1, 0}, {cm, c->n + c->l, 0}, {dc1, c->n, 0}}, nullptr, 1, B);
-    if (rc != RZK_OK) return rc;
-    specs.push_back({dc1, c->n, 0});
-    var = VAR_DPRE;
-  }
+  const std::vector<OpSpec> specs = {{z, c->k, 0}, {t, c->n, 0}, {cm, c->n + c->l, 0}, {d, 1, 0}};
   // open.rs:167-169: the norm predicate on z is fused into the rows that load z (one launch per verify)
-  rc = run_program_checked(c, PG_A1_RELATION, var, specs, accept, 1, B, B, c->verify_bound);
+  int rc = run_program_checked(c, PG_A1_RELATION, 0, specs, accept, 1, B, B, c->verify_bound);
   if (rc != RZK_E_UNSUPPORTED) return rc;
   rc = run_norm(c, z, c->k, c->verify_bound, accept, B, 0, 0);
   if (rc != RZK_OK) return rc;
-  return run_program(c, PG_A1_RELATION, var, specs, accept, 1, B);
+  return run_program(c, PG_A1_RELATION, 0, specs, accept, 1, B);
 }
 
 // =================================================================================================

@@ -457,16 +457,20 @@ RZK_HD int64_t crt_finish(uint32_t stA, int np, const CrtConsts& C) {
 // The challenges of the protocols have kappa coefficients +-1 and zeros elsewhere
 // (reference src/challenge_space.rs:12-33), so d (*) v = sum_s d_s X^s v is kappa signed negacyclic
 // rotations of v.  One wavefront keeps the "extended" image  ext[t] = -v[t] (t < N), v[t-N] (t >= N)
-// in LDS (2N words), where (X^s v)[j] = ext[j - s + N] needs neither a wrap test nor a sign flip, and
-// every lane accumulates E outputs as E/2 adjacent pairs (lane-consecutive LDS words: conflict-free).
+// in LDS (2N words), where (X^s v)[j] = ext[j - s + N] needs neither a wrap test nor a sign flip; the
+// lanes of a wave read consecutive words (conflict-free) at compile-time offsets from one base address.
 // Any multiplier is handled exactly (the cost grows with its number of non-zero coefficients).
-template <int LOGN>
+// Two register layouts: PAIR (coefficients g*128 + 2*lane + {0,1}: 16-byte global accesses, the stand-alone
+// kernel) and the phase-1 layout of the transforms (e*64 + lane: what the row kernel's epilogue uses).
+template <int LOGN, bool PAIR = true>
 struct ShiftGeo {
   static constexpr int N = 1 << LOGN;
   static constexpr int E = N / 64;          // outputs per lane
-  static constexpr int G = E / 2;           // pairs per lane
+  static constexpr int G = E / 2;           // pairs per lane (PAIR layout)
   static constexpr int WORDS = 2 * N;       // LDS words per wavefront
-  RZK_HD static int j(int lane, int i) { return (i >> 1) * 128 + 2 * lane + (i & 1); }   // coefficient of register i
+  RZK_HD static int lane_base(int lane) { return PAIR ? 2 * lane : lane; }
+  static constexpr int off(int i) { return PAIR ? (i >> 1) * 128 + (i & 1) : i * 64; }
+  RZK_HD static int j(int lane, int i) { return lane_base(lane) + off(i); }   // coefficient of register i
 };
 
 // what of v goes into the image: the value itself, or one 16-bit half (two passes keep 64-bit sums exact
@@ -476,53 +480,28 @@ RZK_HD int32_t shift_part(int32_t v, int part) {
   return part == SHIFT_WHOLE ? v : (part == SHIFT_LOW16 ? (int32_t)((uint32_t)v & 0xffffu) : (v >> 16));
 }
 
-template <int LOGN>
+template <int LOGN, bool PAIR>
 RZK_HD void shift_fill(const int32_t* v, int lane, int32_t* ext, int part) {
-  using S = ShiftGeo<LOGN>;
+  using S = ShiftGeo<LOGN, PAIR>;
+  int32_t* base = ext + S::lane_base(lane);
 #pragma unroll
-  for (int g = 0; g < S::G; ++g) {
-    const int j0 = g * 128 + 2 * lane;
-    const int32_t a = shift_part(v[2 * g], part), b = shift_part(v[2 * g + 1], part);
-    ext[S::N + j0] = a;
-    ext[S::N + j0 + 1] = b;
-    ext[j0] = -a;
-    ext[j0 + 1] = -b;
+  for (int i = 0; i < S::E; ++i) {
+    const int32_t a = shift_part(v[i], part);
+    base[S::N + S::off(i)] = a;
+    base[S::off(i)] = -a;
   }
 }
 
-// acc[i] += coef * (X^s v)[j(lane, 2*G0 + i)], i < 2*GN: the output pairs G0 .. G0+GN-1 of one lane.
-// T = int64_t in general; the +-1 form below keeps 32-bit sums when |d|_1 * |v|_inf < 2^30.
-template <int LOGN, typename T, int G0 = 0, int GN = ShiftGeo<LOGN>::G>
+// acc[i - I0] += coef * (X^s v)[j(lane, i)] for the registers I0 .. I0+IN-1 of one lane (T = int64_t: one
+// v_mad_i64_i32 per output).
+template <int LOGN, bool PAIR, typename T, int I0, int IN>
 RZK_HD void shift_accum(T* acc, int lane, int s, int32_t coef, const int32_t* ext) {
-  using S = ShiftGeo<LOGN>;
-  const int32_t* base = ext + (2 * lane + S::N - s);
+  using S = ShiftGeo<LOGN, PAIR>;
+  const int32_t* base = ext + (S::lane_base(lane) + S::N - s);
 #pragma unroll
-  for (int g = 0; g < GN; ++g) {
-    const int32_t x0 = base[(G0 + g) * 128], x1 = base[(G0 + g) * 128 + 1];
-    acc[2 * g] += (T)coef * (T)x0;
-    acc[2 * g + 1] += (T)coef * (T)x1;
-  }
+  for (int i = 0; i < IN; ++i) acc[i] += (T)coef * (T)base[S::off(I0 + i)];
 }
-template <int LOGN>
-RZK_HD void shift_accum_pm(int32_t* acc, int lane, int s, bool minus, const int32_t* ext) {
-  using S = ShiftGeo<LOGN>;
-  const int32_t* base = ext + (2 * lane + S::N - s);
-  if (!minus) {
-#pragma unroll
-    for (int g = 0; g < S::G; ++g) {
-      acc[2 * g] += base[g * 128];
-      acc[2 * g + 1] += base[g * 128 + 1];
-    }
-  } else {
-#pragma unroll
-    for (int g = 0; g < S::G; ++g) {
-      acc[2 * g] -= base[g * 128];
-      acc[2 * g + 1] -= base[g * 128 + 1];
-    }
-  }
-}
-
-// exact integer -> [0,q):  |a| < 2^30 (< q) for the 32-bit form, |a| < 2^62 for the 64-bit form
+// exact integer -> [0,q), |a| < 2^62
 RZK_HD uint32_t zq_from_i64(int64_t a, const CrtConsts& C) {
   const int32_t hi = (int32_t)(a >> 32);          // |hi| < 2^30 < q
   uint32_t lo = (uint32_t)a;                      // < 2^32 < 4q

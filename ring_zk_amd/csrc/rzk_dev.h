@@ -33,7 +33,10 @@ constexpr int kMaxRows = 48;
 constexpr int kMaxTerms = 640;
 constexpr int kMaxAdds = 128;
 
-enum : uint8_t { TERM_KEY = 0, TERM_VEC = 1, TERM_KIND_MASK = 0x7f };
+// TERM_SHIFT: (a_op,a_off) (*) (b_op,b_off) with a sparse `a` (the challenge d), evaluated as signed negacyclic
+// rotations (ShiftGeo, rzk_core.h) instead of transforms.  A row keeps its shift terms behind its transform
+// terms: terms[term0 .. term0+nterms) are KEY / VEC, terms[term0+nterms .. +nshift) are SHIFT.
+enum : uint8_t { TERM_KEY = 0, TERM_VEC = 1, TERM_SHIFT = 2, TERM_KIND_MASK = 0x7f };
 enum : uint8_t { MODE_STORE = 0, MODE_ZERO = 1 };
 // Fused norm predicate (Params::check_*_constraint, src/params.rs:102-118): a term (its b operand) or an
 // addition marked with CHECK also tests sum c^2 < Operands::norm_limit for the polynomial it loads and
@@ -58,6 +61,7 @@ struct Row {
   uint16_t term0, nterms, add0, nadds;
   uint8_t out_op, mode;
   uint16_t out_off;
+  uint16_t nshift, pad;
 };
 // Row groups: consecutive rows made of key products over the SAME operand list (the n rows of a1 over
 // columns n..k-1, the l rows of a2, ...).  One wavefront evaluates a whole group: every shared operand is
@@ -103,7 +107,7 @@ struct LaunchCfg {
 };
 
 int launch_row_program(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows, bool has_vec,
-                       const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf,
+                       bool has_shift, const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf,
                        const DevTables* d_T, const uint32_t* d_tw, uint32_t* d_scratch, uint8_t* d_flags,
                        uint64_t batch);
 int launch_row_program_slots(int logn, const LaunchCfg& cfg, const Program* d_prog, const SlotTable* d_slots,
@@ -120,12 +124,13 @@ int launch_shift_rows(int logn, const LaunchCfg& cfg, const Program* d_prog, uin
                       const DevTables* d_T, uint8_t* d_flags, uint64_t batch);
 // rows per group; 1 = no grouping (at N = 2048 the accumulators cost too many registers: measured slower)
 inline int group_max_for(int logn) { return logn >= 11 ? 1 : kGroupMax; }
-// words of per-wave global scratch the row kernel needs: (max blocks) * 4 waves * N
+// words of per-wave global scratch the row kernel needs: (max blocks) * 4 waves * 2N (Garner word B, shift sums)
 size_t row_scratch_words(int logn, int num_cus);
 int launch_key_transform(int logn, const LaunchCfg& cfg, const int64_t* d_key, uint32_t entries,
                          uint32_t* d_key_ntt, const DevTables* d_T, const uint32_t* d_tw);
 int launch_ntt(int logn, bool inverse, const LaunchCfg& cfg, int prime, const uint32_t* d_in,
                uint32_t* d_out, uint64_t count, const DevTables* d_T, const uint32_t* d_tw);
+int launch_fill_u8(const LaunchCfg& cfg, uint8_t* p, uint8_t value, uint64_t n);
 int launch_addsub(const LaunchCfg& cfg, bool sub, const int64_t* a, const int64_t* b, int64_t* out,
                   uint64_t ncoef, const DevTables* d_T);
 // ok[b] = (all `rows` polys of proof b have sum c^2 < limit), limit = (bound+1)^2 given as hi:lo.

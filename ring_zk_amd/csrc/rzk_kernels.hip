@@ -88,14 +88,16 @@ __device__ __forceinline__ const int64_t* operand_ptr(const Operands& ops, uint3
 #endif
 // Opaque copy of the lane id inside the loops: stops the compiler from hoisting every lane-dependent
 // address out of the loops (where they sit in dozens of VGPRs) at the price of recomputing them per
-// term.  Measured at N = 1024: no gain (123 -> 74 VGPRs but LDS already caps the kernel at 4 waves per
-// SIMD); at N = 2048 it takes the kernel from 254 VGPRs (1 wave per SIMD) to ~125 (4 waves).
+// term.  At N = 1024 it costs the transform-only rows ~5 % (123 -> 87 VGPRs, but LDS already caps the kernel
+// at 4 waves per SIMD), so there it is used only (template flag OPQ) by the rows that start with a shift term,
+// which it keeps below 128 VGPRs (144 -> 101); at N = 2048 it takes the kernel from 254 VGPRs (1 wave per
+// SIMD) to ~125 (4 waves).
 #ifndef RZK_OPAQUE_LANE_MIN_LOGN
 #define RZK_OPAQUE_LANE_MIN_LOGN 11
 #endif
-#define RZK_OPAQUE(v)                                              \
-  do {                                                             \
-    if (LOGN >= RZK_OPAQUE_LANE_MIN_LOGN) asm volatile("" : "+v"(v)); \
+#define RZK_OPAQUE(v)                                                     \
+  do {                                                                    \
+    if (LOGN >= RZK_OPAQUE_LANE_MIN_LOGN || OPQ) asm volatile("" : "+v"(v)); \
   } while (0)
 
 // Load one coefficient polynomial (coalesced phase-1 layout), lift it into prime field `pc` and,
@@ -166,8 +168,113 @@ __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict
 #define RZK_ROW_MIN_WAVES 1   // minimum waves per SIMD the row kernels are compiled for (register budget)
 #endif
 
+// ---- challenge products as signed rotations (ShiftGeo, rzk_core.h): shared by shift_row_kernel and the
+// shift terms of row_kernel ---------------------------------------------------------------------------------
+template <int LOGN>
+__device__ __forceinline__ void load_pairs(int32_t* v, const int64_t* __restrict__ src, int lane) {
+  using S = ShiftGeo<LOGN>;
+  const int4* __restrict__ p = reinterpret_cast<const int4*>(src);
+#pragma unroll
+  for (int g = 0; g < S::G; ++g) {
+    const int4 t = p[g * 64 + lane];   // coefficients g*128 + 2*lane, +1 (low words of two int64)
+    v[2 * g] = t.x;
+    v[2 * g + 1] = t.z;
+  }
+}
+
+// walk the non-zero coefficients of the multiplier (registers a[], lane-distributed in layout PAIR) and add
+// the rotations into IN outputs of every lane; `ext` already points at the first of them
+template <int LOGN, bool PAIR, int IN>
+__device__ __forceinline__ void shift_scan(int64_t* acc, const int32_t* a, int lane, const int32_t* ext) {
+  using S = ShiftGeo<LOGN, PAIR>;
+#pragma unroll
+  for (int i = 0; i < S::E; ++i) {
+    uint64_t mask = __ballot(a[i] != 0);
+    while (mask) {
+      const int l = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const int32_t coef = __builtin_amdgcn_readlane(a[i], l);
+      const int s = S::off(i) + (PAIR ? 2 * l : l);
+      int ln = lane;
+      asm volatile("" : "+v"(ln));   // keeps the 16 per-register base addresses from being hoisted into VGPRs
+      shift_accum<LOGN, PAIR, int64_t, 0, IN>(acc, ln, s, coef, ext);
+    }
+  }
+}
+// (Taking two non-zeros per trip, or sixteen outputs per scan, to keep more LDS reads in flight was measured
+// slower: the extra registers cost a wave per SIMD.)
+
+// res[] (in [0,q)) +/-= (a (*) v) mod q for one product term; a[] holds the multiplier's low words in layout
+// PAIR, pv points at the other operand.  ext: the wave's 2N-word LDS image.  Wave-uniform control flow.
+// TO_MEM: res is a per-wave line in global memory indexed by coefficient (each lane touches only its own
+// coefficients) and `fresh` says that it holds nothing yet; otherwise res are the lane's E registers.
+// Sums are exact 64-bit integers (v_mad_i64_i32) as long as |a|_1 |v|_inf < 2^62; beyond that v goes in as
+// two 16-bit halves.  Eight of a lane's outputs are accumulated at a time (register budget).
+template <int LOGN, bool PAIR, bool TO_MEM>
+__device__ __forceinline__ void shift_product(uint32_t* res, bool fresh, bool minus, const int32_t* a,
+                                              const int64_t* __restrict__ pv, int lane, int32_t* ext,
+                                              const DevTables& T) {
+  using S = ShiftGeo<LOGN, PAIR>;
+  constexpr int E = S::E;
+  constexpr int H = 8;                 // outputs per scan; chunk c covers registers c*H .. c*H+H-1
+  constexpr int NCH = E / H;
+  const uint32_t q = T.crt.q;
+  int npass = 1;
+#pragma unroll 1
+  for (int pass = 0; pass < npass; ++pass) {
+    {
+      int32_t v[E];
+      if (PAIR) {
+        load_pairs<LOGN>(v, pv, lane);
+      } else {
+#pragma unroll
+        for (int i = 0; i < E; ++i) v[i] = (int32_t)pv[S::j(lane, i)];
+      }
+      if (pass == 0) {
+        uint64_t suma = 0;
+        uint32_t maxv = 0;
+#pragma unroll
+        for (int i = 0; i < E; ++i) {
+          suma += (uint32_t)(a[i] < 0 ? -a[i] : a[i]);
+          const uint32_t vv = (uint32_t)(v[i] < 0 ? -v[i] : v[i]);
+          maxv = vv > maxv ? vv : maxv;
+        }
+        const double bound = (double)wave_sum_u64(suma) * (double)wave_max_u32(maxv);   // |exact product|_inf
+        npass = __builtin_amdgcn_readfirstlane(bound < 4.0e18 ? 1 : 2);                  // 4.0e18 < 2^62
+      }
+      wave_sync();   // earlier reads of the image are done before it is overwritten
+      shift_fill<LOGN, PAIR>(v, lane, ext, npass == 1 ? SHIFT_WHOLE : (pass == 0 ? SHIFT_LOW16 : SHIFT_HIGH16));
+      wave_sync();
+    }
+#pragma unroll 1
+    for (int ch = 0; ch < NCH; ++ch) {
+      int64_t acc[H];
+#pragma unroll
+      for (int i = 0; i < H; ++i) acc[i] = 0;
+      shift_scan<LOGN, PAIR, H>(acc, a, lane, ext + ch * (64 * H));   // off(c*H + i) = off(i) + 64 H c in both layouts
+#pragma unroll
+      for (int i = 0; i < H; ++i) {
+        uint32_t u = zq_from_i64(acc[i], T.crt);
+        if (pass) u = montq_u(u, T.crt.r48q, T.crt);   // high halves carry the weight 2^16
+        if (TO_MEM) {
+          uint32_t* slot = res + S::j(lane, i) + ch * (64 * H);
+          const uint32_t cur = (fresh && pass == 0) ? 0u : *slot;
+          *slot = minus ? subq(cur, u, q) : addq(cur, u, q);
+        } else {
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {   // register index c*H + i, selected without dynamic indexing
+            const uint32_t cur = res[c * H + i];
+            const uint32_t nw = minus ? subq(cur, u, q) : addq(cur, u, q);
+            res[c * H + i] = c == ch ? nw : cur;
+          }
+        }
+      }
+    }
+  }
+}
+
 // acc +/- (term) for prime `pi`, transforming the term's operands in the wave.
-template <int LOGN, bool HAS_VEC>
+template <int LOGN, bool HAS_VEC, bool OPQ = false>
 __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const Operands& ops, uint32_t b,
                                             uint32_t bo, int lane, uint32_t* lds, const uint32_t* __restrict__ twf,
                                             const PrimeConsts& pc, int pi, const uint32_t* __restrict__ key_ntt,
@@ -233,7 +340,7 @@ __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const 
 
 // inverse transform of the prime-`pi` accumulator and fold into the Garner state: word A in LDS, word B
 // (third prime only) in the per-wave global scratch line.  acc is clobbered.
-template <int LOGN>
+template <int LOGN, bool OPQ = false>
 __device__ __forceinline__ void inverse_and_fold(int pi, int np, uint32_t* acc, int lane, uint32_t* lds,
                                                  const uint32_t* __restrict__ twi, const PrimeConsts& pc,
                                                  uint32_t* st_lds, uint32_t* __restrict__ st_glb, const DevTables& T) {
@@ -273,7 +380,8 @@ __device__ __forceinline__ void inverse_and_fold(int pi, int np, uint32_t* acc, 
 template <int LOGN>
 __device__ __forceinline__ void row_epilogue(const Program* __restrict__ prog, const Row row, const Operands& ops,
                                              uint32_t b, uint32_t bo, int lane, bool has_terms, int np,
-                                             const uint32_t* st_lds, const DevTables& T, uint8_t* __restrict__ flags) {
+                                             const uint32_t* st_lds, const DevTables& T, uint8_t* __restrict__ flags,
+                                             const uint32_t* __restrict__ st_sh = nullptr) {
   using G = Geo<LOGN>;
   constexpr int E = G::E;
   constexpr int N = G::N;
@@ -290,6 +398,10 @@ __device__ __forceinline__ void row_epilogue(const Program* __restrict__ prog, c
     } else {
 #pragma unroll
       for (int i = 0; i < CH; ++i) u[i] = 0;
+    }
+    if (st_sh) {   // sum of the row's shift terms, left by the same lanes
+#pragma unroll
+      for (int i = 0; i < CH; ++i) u[i] = addq(u[i], st_sh[G::j_p1(lane, e0 + i)], q);
     }
 #pragma unroll 1
     for (uint32_t a = 0; a < row.nadds; ++a) {
@@ -350,7 +462,7 @@ __device__ __forceinline__ int primes_for(double bound, const DevTables& T) {
   return __builtin_amdgcn_readfirstlane(np);
 }
 
-template <int LOGN, bool HAS_VEC>
+template <int LOGN, bool HAS_VEC, bool HAS_SHIFT>
 __global__ void __launch_bounds__(256, RZK_ROW_MIN_WAVES)
 row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t* __restrict__ key_ntt,
            const double* __restrict__ key_inf, const DevTables* __restrict__ Tp,
@@ -362,9 +474,12 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  uint32_t* lds = smem + wave * G::LDS_WORDS;               // transposition slab
-  uint32_t* st_lds = smem + 4 * G::LDS_WORDS + wave * N;    // Garner state A (one word per coefficient)
-  uint32_t* st_glb = scratch + ((size_t)blockIdx.x * 4 + wave) * N;   // state B, only touched when np == 3
+  // per wave: transposition slab, then Garner state A (one word per coefficient); the two together also hold
+  // the 2N-word image of a shift term, which is finished before the transforms start
+  uint32_t* lds = smem + wave * (G::LDS_WORDS + N);
+  uint32_t* st_lds = lds + G::LDS_WORDS;
+  uint32_t* st_glb = scratch + ((size_t)blockIdx.x * 4 + wave) * (2 * N);   // state B, only touched when np == 3
+  uint32_t* st_sh = st_glb + N;                                             // sum of the row's shift terms mod q
   const DevTables& T = *Tp;
   const uint32_t nrows = prog->nrows;
 
@@ -373,6 +488,23 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
     const uint32_t rowi = task - b * nrows;
     const uint32_t bo = ops.group > 1 ? b / ops.group : b;
     const Row row = prog->rows[rowi];
+
+    const bool has_shift = HAS_SHIFT && row.nshift > 0;
+    if (has_shift) {
+      // challenge products first (rotations in LDS); their sum mod q is built in the wave's scratch line (every
+      // lane reads and writes only its own coefficients) and waits there for the epilogue
+#pragma unroll 1
+      for (uint32_t t = 0; t < row.nshift; ++t) {
+        const Term tm = prog->terms[row.term0 + row.nterms + t];
+        const int64_t* __restrict__ pa = operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N);
+        const int64_t* __restrict__ pv = operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N);
+        int32_t a[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) a[e] = (int32_t)pa[G::j_p1(lane, e)];
+        shift_product<LOGN, false, true>(st_sh, t == 0, tm.sign < 0, a, pv, lane, reinterpret_cast<int32_t*>(lds), T);
+      }
+      wave_sync();   // the image is dead: the slab and state words may be overwritten
+    }
 
     const bool has_terms = row.nterms > 0;
     int np = kMaxPrimes;
@@ -388,13 +520,13 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
         for (int c = 0; c < E; ++c) acc[c] = 0;
 #pragma unroll 1
         for (uint32_t t = 0; t < row.nterms; ++t)
-          term_direct<LOGN, HAS_VEC>(acc, prog->terms[row.term0 + t], ops, b, bo, lane, lds, twf, pc, pi, key_ntt,
+          term_direct<LOGN, HAS_VEC, HAS_SHIFT>(acc, prog->terms[row.term0 + t], ops, b, bo, lane, lds, twf, pc, pi, key_ntt,
                                      key_inf, first, bound, flags);
         if (first) np = primes_for(bound, T);
-        inverse_and_fold<LOGN>(pi, np, acc, lane, lds, twf + kTableLen, pc, st_lds, st_glb, T);
+        inverse_and_fold<LOGN, HAS_SHIFT>(pi, np, acc, lane, lds, twf + kTableLen, pc, st_lds, st_glb, T);
       }
     }
-    row_epilogue<LOGN>(prog, row, ops, b, bo, lane, has_terms, np, st_lds, T, flags);
+    row_epilogue<LOGN>(prog, row, ops, b, bo, lane, has_terms, np, st_lds, T, flags, has_shift ? st_sh : nullptr);
   }
 }
 
@@ -408,43 +540,12 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
 // is +-1-valued and |d|_1 |v|_inf < 2^30, in 64 bits (v_mad_i64_i32) below 2^62, and in two 16-bit passes
 // beyond that.
 // =============================================================================================
-template <int LOGN>
-__device__ __forceinline__ void load_pairs(int32_t* v, const int64_t* __restrict__ src, int lane) {
-  using S = ShiftGeo<LOGN>;
-  const int4* __restrict__ p = reinterpret_cast<const int4*>(src);
-#pragma unroll
-  for (int g = 0; g < S::G; ++g) {
-    const int4 t = p[g * 64 + lane];   // coefficients g*128 + 2*lane, +1 (low words of two int64)
-    v[2 * g] = t.x;
-    v[2 * g + 1] = t.z;
-  }
-}
-
-// walk the non-zero coefficients of the multiplier (registers a[], lane-distributed) and add the rotations
-// into the output pairs G0 .. G0+GN-1 of every lane
-template <int LOGN, typename T, bool PM, int G0, int GN>
-__device__ __forceinline__ void shift_scan(T* acc, const int32_t* a, int lane, const int32_t* ext) {
-  using S = ShiftGeo<LOGN>;
-#pragma unroll
-  for (int i = 0; i < S::E; ++i) {
-    uint64_t mask = __ballot(a[i] != 0);
-    while (mask) {
-      const int l = __builtin_ctzll(mask);
-      mask &= mask - 1;
-      const int32_t coef = __builtin_amdgcn_readlane(a[i], l);
-      const int s = (i >> 1) * 128 + 2 * l + (i & 1);
-      if constexpr (PM) shift_accum_pm<LOGN>(reinterpret_cast<int32_t*>(acc), lane, s, coef < 0, ext);
-      else shift_accum<LOGN, T, G0, GN>(acc, lane, s, coef, ext);
-    }
-  }
-}
-
 #ifndef RZK_SHIFT_MIN_WAVES
 #define RZK_SHIFT_MIN_WAVES 1
 #endif
 template <int LOGN>
 struct ShiftCfg {   // waves per workgroup: one wave's image is 8 * N bytes of LDS, 32 KiB per workgroup at most
-  static constexpr int WPB = LOGN <= 10 ? 4 : 2;
+  static constexpr int WPB = 4;
 };
 
 template <int LOGN>
@@ -482,73 +583,10 @@ shift_row_kernel(const Program* __restrict__ prog, const Operands ops, const Dev
 #pragma unroll 1
     for (uint32_t t = 0; t < row.nterms; ++t) {
       const Term tm = prog->terms[row.term0 + t];
-      int32_t a[E], v[E];
+      int32_t a[E];
       load_pairs<LOGN>(a, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), lane);
-      load_pairs<LOGN>(v, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane);
-      uint64_t suma = 0;
-      uint32_t maxa = 0, maxv = 0;
-#pragma unroll
-      for (int i = 0; i < E; ++i) {
-        const uint32_t aa = (uint32_t)(a[i] < 0 ? -a[i] : a[i]);
-        const uint32_t vv = (uint32_t)(v[i] < 0 ? -v[i] : v[i]);
-        suma += aa;
-        maxa = aa > maxa ? aa : maxa;
-        maxv = vv > maxv ? vv : maxv;
-      }
-      const double l1a = (double)wave_sum_u64(suma);
-      const uint32_t ainf = wave_max_u32(maxa);
-      const double bound = l1a * (double)wave_max_u32(maxv);   // |exact product|_inf <= bound
-      const int mode = __builtin_amdgcn_readfirstlane(
-          (ainf <= 1u && bound < 1073741824.0) ? 0 : (bound < 4.0e18 ? 1 : 2));   // 2^30 ; < 2^62
-      uint32_t tr[E];
-      if (mode == 0) {
-        wave_sync();   // earlier reads of the images are done before they are overwritten
-        shift_fill<LOGN>(v, lane, slab, SHIFT_WHOLE);
-        wave_sync();
-        int32_t acc[E];
-#pragma unroll
-        for (int i = 0; i < E; ++i) acc[i] = 0;
-        shift_scan<LOGN, int32_t, true, 0, S::G>(acc, a, lane, slab);
-#pragma unroll
-        for (int i = 0; i < E; ++i) tr[i] = zq_from_centered(acc[i], q);
-      } else {
-#pragma unroll 1
-        for (int pass = 0; pass < mode; ++pass) {
-          wave_sync();
-          shift_fill<LOGN>(v, lane, slab, mode == 1 ? SHIFT_WHOLE : (pass == 0 ? SHIFT_LOW16 : SHIFT_HIGH16));
-          wave_sync();
-          // 64-bit sums, half of the outputs at a time (register budget); high halves carry the weight 2^16
-          {
-            int64_t acc[E / 2];
-#pragma unroll
-            for (int i = 0; i < E / 2; ++i) acc[i] = 0;
-            shift_scan<LOGN, int64_t, false, 0, S::G / 2>(acc, a, lane, slab);
-#pragma unroll
-            for (int i = 0; i < E / 2; ++i) {
-              const uint32_t u = zq_from_i64(acc[i], T.crt);
-              tr[i] = pass == 0 ? u : addq(tr[i], montq_u(u, T.crt.r48q, T.crt), q);
-            }
-          }
-          {
-            int64_t acc[E / 2];
-#pragma unroll
-            for (int i = 0; i < E / 2; ++i) acc[i] = 0;
-            shift_scan<LOGN, int64_t, false, S::G / 2, S::G / 2>(acc, a, lane, slab);
-#pragma unroll
-            for (int i = 0; i < E / 2; ++i) {
-              const uint32_t u = zq_from_i64(acc[i], T.crt);
-              tr[E / 2 + i] = pass == 0 ? u : addq(tr[E / 2 + i], montq_u(u, T.crt.r48q, T.crt), q);
-            }
-          }
-        }
-      }
-      if (tm.sign >= 0) {
-#pragma unroll
-        for (int i = 0; i < E; ++i) res[i] = addq(res[i], tr[i], q);
-      } else {
-#pragma unroll
-        for (int i = 0; i < E; ++i) res[i] = subq(res[i], tr[i], q);
-      }
+      shift_product<LOGN, true, false>(res, false, tm.sign < 0, a, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane,
+                                       slab, T);
     }
 
     if (row.nadds > 0) {
@@ -1232,37 +1270,42 @@ static inline unsigned grid_for(uint64_t tasks, int num_cus, int waves_per_block
     if (e_ != hipSuccess) return (int)e_;       \
   } while (0)
 
-size_t row_scratch_words(int logn, int num_cus) { return (size_t)num_cus * 8 * 4 * ((size_t)1 << logn); }
+size_t row_scratch_words(int logn, int num_cus) { return (size_t)num_cus * 8 * 4 * ((size_t)2 << logn); }
 
-template <int LOGN, bool HAS_VEC>
+template <int LOGN, bool HAS_VEC, bool HAS_SHIFT>
 static int launch_row_t(const LaunchCfg& cfg, const Program* d_prog, const Operands& ops,
                         const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T,
                         const uint32_t* d_tw, uint32_t* d_scratch, uint8_t* d_flags, uint32_t ntasks) {
   using G = Geo<LOGN>;
   const size_t lds = 4 * (G::LDS_WORDS + G::N) * sizeof(uint32_t);   // transposition slab + Garner state per wave
   const unsigned grid = grid_for(ntasks, cfg.num_cus);               // <= num_cus * 8 blocks (scratch sizing)
-  hipLaunchKernelGGL((row_kernel<LOGN, HAS_VEC>), dim3(grid), dim3(256), lds, (hipStream_t)cfg.stream, d_prog,
+  hipLaunchKernelGGL((row_kernel<LOGN, HAS_VEC, HAS_SHIFT>), dim3(grid), dim3(256), lds, (hipStream_t)cfg.stream, d_prog,
                      ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
   RZK_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_row_program(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows, bool has_vec,
-                       const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf,
+                       bool has_shift, const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf,
                        const DevTables* T, const uint32_t* d_tw, uint32_t* d_scratch, uint8_t* d_flags,
                        uint64_t batch) {
   if (batch == 0 || nrows == 0) return 0;
   if (batch * nrows >= (1ull << 32)) return -2;   // task index is 32-bit
   const uint32_t ntasks = (uint32_t)(batch * nrows);
-#define RZK_ROW_CASE(L)                                                                                                 \
-  case L:                                                                                                               \
-    return has_vec ? launch_row_t<L, true>(cfg, d_prog, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks) \
-                   : launch_row_t<L, false>(cfg, d_prog, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
+#define RZK_ROW_ARGS cfg, d_prog, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks
+#define RZK_ROW_CASE(L)                                                                                        \
+  case L:                                                                                                      \
+    if (has_shift)                                                                                             \
+      return has_vec ? launch_row_t<L, true, true>(RZK_ROW_ARGS) : launch_row_t<L, false, true>(RZK_ROW_ARGS); \
+    return has_vec ? launch_row_t<L, true, false>(RZK_ROW_ARGS) : launch_row_t<L, false, false>(RZK_ROW_ARGS);
   switch (logn) {
     RZK_ROW_CASE(9)
     RZK_ROW_CASE(10)
-    RZK_ROW_CASE(11)
+    case 11:   // shift terms are not built for N = 2048 (rzk_api.cpp, shift_ok)
+      if (has_shift) return -1;
+      return has_vec ? launch_row_t<11, true, false>(RZK_ROW_ARGS) : launch_row_t<11, false, false>(RZK_ROW_ARGS);
   }
+#undef RZK_ROW_ARGS
 #undef RZK_ROW_CASE
   return -1;
 }
@@ -1288,7 +1331,6 @@ int launch_shift_rows(int logn, const LaunchCfg& cfg, const Program* d_prog, uin
   switch (logn) {
     case 9: return launch_shift_t<9>(cfg, d_prog, ops, T, d_flags, ntasks);
     case 10: return launch_shift_t<10>(cfg, d_prog, ops, T, d_flags, ntasks);
-    case 11: return launch_shift_t<11>(cfg, d_prog, ops, T, d_flags, ntasks);
   }
   return -1;
 }
@@ -1407,6 +1449,19 @@ int launch_ntt(int logn, bool inverse, const LaunchCfg& cfg, int prime, const ui
     case 11: return launch_ntt_t<11>(inverse, cfg, prime, d_in, d_out, count, T, d_tw);
   }
   return -1;
+}
+
+// flags[i] = value: one small launch (hipMemsetAsync's fill kernel takes ~4.5 us for 4 KiB on this stack)
+__global__ void __launch_bounds__(256) fill_u8_kernel(uint8_t* __restrict__ p, uint8_t value, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) p[i] = value;
+}
+int launch_fill_u8(const LaunchCfg& cfg, uint8_t* p, uint8_t value, uint64_t n) {
+  if (n == 0) return 0;
+  uint64_t blocks = (n + 255) / 256;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(fill_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)cfg.stream, p, value, n);
+  RZK_LAUNCH_CHECK();
+  return 0;
 }
 
 int launch_addsub(const LaunchCfg& cfg, bool sub, const int64_t* a, const int64_t* b, int64_t* out,

@@ -117,39 +117,34 @@ int polymul(int np, uint64_t q, const int64_t* a, const int64_t* b, int64_t* out
 }
 
 // out = d * v in Z_q[X]/(X^N+1), centred, by the shift-add scheme of the challenge products (ShiftGeo):
-// mode 0 = 32-bit sums of +-1 rotations, 1 = 64-bit sums, 2 = two 16-bit passes.
-template <int LOGN>
-int shift_product(int mode, uint64_t q, const int64_t* d, const int64_t* v, int64_t* out) {
-  using S = ShiftGeo<LOGN>;
+// passes = 1: whole values, 2: two 16-bit halves; outputs accumulated half a lane at a time as in the kernels.
+template <int LOGN, bool PAIR>
+int shift_product(int passes, uint64_t q, const int64_t* d, const int64_t* v, int64_t* out) {
+  using S = ShiftGeo<LOGN, PAIR>;
+  constexpr int H = S::E / 2;
   CrtConsts C;
   if (!host::make_crt_consts(q, C)) return -1;
-  static int32_t slab[S::WORDS];
+  static int32_t ext[S::WORDS];
   static int32_t vr[64][S::E];
   static uint32_t tr[64][S::E];
   for (int l = 0; l < 64; ++l)
     for (int i = 0; i < S::E; ++i) vr[l][i] = (int32_t)v[S::j(l, i)];
-  const int passes = mode == 2 ? 2 : 1;
   for (int pass = 0; pass < passes; ++pass) {
-    const int part = mode == 2 ? (pass == 0 ? SHIFT_LOW16 : SHIFT_HIGH16) : SHIFT_WHOLE;
-    for (int l = 0; l < 64; ++l) shift_fill<LOGN>(vr[l], l, slab, part);
-    for (int l = 0; l < 64; ++l) {
-      int32_t a32[S::E] = {0};
-      int64_t a64[S::E] = {0};
-      for (int s = 0; s < S::N; ++s) {
-        const int32_t coef = (int32_t)d[s];
-        if (coef == 0) continue;
-        if (mode == 0) {
-          if (coef != 1 && coef != -1) return -3;
-          shift_accum_pm<LOGN>(a32, l, s, coef < 0, slab);
-        } else {
-          shift_accum<LOGN, int64_t>(a64, l, s, coef, slab);
+    const int part = passes == 2 ? (pass == 0 ? SHIFT_LOW16 : SHIFT_HIGH16) : SHIFT_WHOLE;
+    for (int l = 0; l < 64; ++l) shift_fill<LOGN, PAIR>(vr[l], l, ext, part);
+    for (int l = 0; l < 64; ++l)
+      for (int half = 0; half < 2; ++half) {
+        int64_t acc[H] = {0};
+        for (int s = 0; s < S::N; ++s) {
+          const int32_t coef = (int32_t)d[s];
+          if (coef != 0) shift_accum<LOGN, PAIR, int64_t, 0, H>(acc, l, s, coef, ext + half * (S::N / 2));
+        }
+        for (int i = 0; i < H; ++i) {
+          const uint32_t u = zq_from_i64(acc[i], C);
+          uint32_t& t = tr[l][half * H + i];
+          t = pass == 0 ? u : addq(t, montq_u(u, C.r48q, C), C.q);
         }
       }
-      for (int i = 0; i < S::E; ++i) {
-        const uint32_t u = mode == 0 ? zq_from_centered(a32[i], C.q) : zq_from_i64(a64[i], C);
-        tr[l][i] = pass == 0 ? u : addq(tr[l][i], montq_u(u, C.r48q, C), C.q);
-      }
-    }
   }
   for (int l = 0; l < 64; ++l)
     for (int i = 0; i < S::E; ++i) out[S::j(l, i)] = center_from_zq(tr[l][i], C);
@@ -159,11 +154,11 @@ int shift_product(int mode, uint64_t q, const int64_t* d, const int64_t* v, int6
 }  // namespace
 
 extern "C" {
-int emul_shift_product(int logn, int mode, uint64_t q, const int64_t* d, const int64_t* v, int64_t* out) {
+int emul_shift_product(int logn, int pair, int passes, uint64_t q, const int64_t* d, const int64_t* v, int64_t* out) {
   switch (logn) {
-    case 9: return shift_product<9>(mode, q, d, v, out);
-    case 10: return shift_product<10>(mode, q, d, v, out);
-    case 11: return shift_product<11>(mode, q, d, v, out);
+    case 9: return pair ? shift_product<9, true>(passes, q, d, v, out) : shift_product<9, false>(passes, q, d, v, out);
+    case 10: return pair ? shift_product<10, true>(passes, q, d, v, out) : shift_product<10, false>(passes, q, d, v, out);
+    case 11: return pair ? shift_product<11, true>(passes, q, d, v, out) : shift_product<11, false>(passes, q, d, v, out);
   }
   return -1;
 }

@@ -114,17 +114,18 @@ def test_emulated_polymul_fewer_primes(emul, logn):
     assert np.array_equal(_polymul(emul, logn, 1, a, b), O.poly_mul(a, b))
 
 
+@pytest.mark.parametrize("pair", [1, 0])
 @pytest.mark.parametrize("logn", [9, 10, 11])
-def test_emulated_shift_product(emul, logn):
-    """Challenge products as signed negacyclic rotations (ShiftGeo in rzk_core.h) in all three sum widths."""
+def test_emulated_shift_product(emul, logn, pair):
+    """Challenge products as signed negacyclic rotations (ShiftGeo in rzk_core.h), one and two passes."""
     N = 1 << logn
     rng = np.random.default_rng(500 + logn)
 
-    def run(mode, d, v):
+    def run(passes, d, v):
         out = np.empty(N, dtype=np.int64)
         d = np.ascontiguousarray(d, dtype=np.int64)
         v = np.ascontiguousarray(v, dtype=np.int64)
-        assert emul.emul_shift_product(logn, mode, C.c_uint64(Q), _i64p(d), _i64p(v), _i64p(out)) == 0
+        assert emul.emul_shift_product(logn, pair, passes, C.c_uint64(Q), _i64p(d), _i64p(v), _i64p(out)) == 0
         return out
 
     d = np.zeros(N, dtype=np.int64)
@@ -132,11 +133,11 @@ def test_emulated_shift_product(emul, logn):
     d[pos] = rng.choice([-1, 1], 36)
     d[0], d[1], d[N - 1], d[N - 2] = 1, -1, -1, 1            # both parities at both ends
     r = rng.integers(-1, 2, N, dtype=np.int64)
-    assert np.array_equal(run(0, d, r), O.poly_mul(d, r))
+    assert np.array_equal(run(1, d, r), O.poly_mul(d, r))
     c1 = rng.integers(-HALF, HALF + 1, N, dtype=np.int64)     # full-range commitment row
     c1[:2] = [HALF, -HALF]
-    for mode in (1, 2):
-        assert np.array_equal(run(mode, d, c1), O.poly_mul(d, c1))
+    for passes in (1, 2):
+        assert np.array_equal(run(passes, d, c1), O.poly_mul(d, c1))
     dd = rng.integers(-HALF, HALF + 1, N, dtype=np.int64)     # dense full-range multiplier: sums up to 2^72
     dd[:2] = [-HALF, HALF]
     assert np.array_equal(run(2, dd, c1), O.poly_mul(dd, c1))

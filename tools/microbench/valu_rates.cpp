@@ -92,6 +92,7 @@ DEF_KERNEL_U32(lshl_add, "v_lshl_add_u32 %0, %0, 1, %1")
 
 // D.u64 = S0.u32 * S1.u32 + S2.u64 ; chain through the 64-bit addend.
 DEF_KERNEL_U64(mad_u64_u32, "v_mad_u64_u32 %0, vcc, %1, %1, %0")
+DEF_KERNEL_U64(mad_i64_i32, "v_mad_i64_i32 %0, vcc, %1, %1, %0")
 
 // fp64 kernels
 #define DEF_KERNEL_F64(NAME, ASM)                                                        \
@@ -271,6 +272,7 @@ int main() {
       {"v_mov_dpp(xor1)", k_mov_dpp_xor1, 64},
       {"v_fma_f32", k_fma_f32, 64},         {"v_mul_lo_u32", k_mul_lo_u32, 64},
       {"v_mul_hi_u32", k_mul_hi_u32, 64},   {"v_mad_u64_u32", k_mad_u64_u32, 64},
+      {"v_mad_i64_i32", k_mad_i64_i32, 64},
       {"v_mul_u32_u24", k_mul_u32_u24, 64}, {"v_mul_hi_u32_u24", k_mul_hi_u32_u24, 64},
       {"v_mad_u32_u24", k_mad_u32_u24, 64}, {"v_fma_f64", k_fma_f64, 64},
       {"v_mul_f64", k_mul_f64, 64},         {"v_add_f64", k_add_f64, 64},

@@ -118,6 +118,22 @@ uint32_t rzk_ntt_psi(int prime, uint32_t N);
 /* position, in the NTT-domain layout, of element j of the standard bit-reversed-order transform */
 uint32_t rzk_ntt_layout_index(uint32_t N, uint32_t j);
 
+/* ---- commitment scheme (src/commit.rs) ------------------------------------------------------------------ */
+/* CommitmentKey::commit (commit.rs:88-128) with the randomness supplied by the caller:
+ * c = [a1;a2].r + [0_n ; x] (commit.rs:109-125); ok[b] = check_commit_constraint(r_b) — the reference
+ * resamples r until it holds (commit.rs:98-107), here the caller resamples the proofs with ok == 0.
+ * x:[B][l][N] r:[B][k][N] -> c:[B][n+l][N] ok:[B] (ok may be NULL) */
+int rzk_commit_batch(rzk_ctx* ctx, const int64_t* x, const int64_t* r, int64_t* c, uint8_t* ok, size_t B);
+int rzk_commit_batch_dev(rzk_ctx* ctx, const int64_t* x, const int64_t* r, int64_t* c, uint8_t* ok, size_t B);
+/* Commitment::verify (commit.rs:173-210) of the opening (x, r, f):
+ * ok[b] = check_commit_constraint(r) && ( f == NULL ?  [a1;a2].r + [0_n;x] == c
+ *                                                   :  c (.) f == [a1;a2].r + [0_n;x] (.) f )
+ * c:[B][n+l][N] x:[B][l][N] r:[B][k][N] f:[B][N] or NULL (Opening::f = None) -> ok:[B] */
+int rzk_commitment_verify_batch(rzk_ctx* ctx, const int64_t* c, const int64_t* x, const int64_t* r,
+                                const int64_t* f, uint8_t* ok, size_t B);
+int rzk_commitment_verify_batch_dev(rzk_ctx* ctx, const int64_t* c, const int64_t* x, const int64_t* r,
+                                    const int64_t* f, uint8_t* ok, size_t B);
+
 /* ---- OpenProof phases (src/prove/open.rs) --------------------------------------------------------- */
 /* OpenProofProver::commit (open.rs:80-103) with the randomness supplied by the caller:
  * c = [a1;a2].r + [0;x] (commit.rs:125), t = a1.y (open.rs:97); ok[b] = check_commit_constraint(r)

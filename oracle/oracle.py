@@ -210,10 +210,14 @@ def commit(P: Params, A, x, r):
     return c, bool(ok)
 
 
-def commitment_verify(P: Params, A, c, x, r) -> bool:
+def commitment_verify(P: Params, A, c, x, r, f=None) -> bool:
+    """Commitment::verify (commit.rs:173-210); f = None or the scalar polynomial of the relaxed opening."""
     A, c, x, r = _a(A), _a(c), _a(x), _a(r)
     cp = P.c()
-    return bool(lib().rzko_commitment_verify(C.byref(cp), _p(A), _p(c), _p(x), _p(r)))
+    if f is None:
+        return bool(lib().rzko_commitment_verify(C.byref(cp), _p(A), _p(c), _p(x), _p(r)))
+    f = _a(f)
+    return bool(lib().rzko_commitment_verify_f(C.byref(cp), _p(A), _p(c), _p(x), _p(r), _p(f)))
 
 
 def open_commit(P: Params, A, x, r, y):

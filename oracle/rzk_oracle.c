@@ -253,11 +253,37 @@ int rzko_commit(const rzko_params* P, const int64_t* A, const int64_t* x, const 
 int rzko_commitment_verify(const rzko_params* P, const int64_t* A, const int64_t* c,
                            const int64_t* x, const int64_t* r) {
   /* commit.rs:173-210 with f = None: constraint(r) && a.dot(r).add(z) == c */
-  const uint32_t N = P->N, n = P->n, l = P->l;
-  int64_t* c2 = (int64_t*)malloc(sizeof(int64_t) * (size_t)(n + l) * N);
-  int ok = rzko_commit(P, A, x, r, c2);
-  if (ok) ok = memcmp(c, c2, sizeof(int64_t) * (size_t)(n + l) * N) == 0;
-  free(c2);
+  return rzko_commitment_verify_f(P, A, c, x, r, NULL);
+}
+
+int rzko_commitment_verify_f(const rzko_params* P, const int64_t* A, const int64_t* c,
+                             const int64_t* x, const int64_t* r, const int64_t* f) {
+  /* commit.rs:173-210.  f = None (NULL): a.dot(r).add(z) == c ; f = Some: c.cmul(f) == a.dot(r).add(z.cmul(f)),
+   * z = [0_n ; x] (commit.rs:190-195); false at once when r violates the commit constraint (commit.rs:183-185). */
+  const uint32_t N = P->N, n = P->n, k = P->k, l = P->l;
+  const size_t rows = (size_t)n + l;
+  if (!rzko_check_norm(N, k, r, rzko_commit_bound(P->b, P->kappa, k, N))) return 0;
+  int64_t* ar = (int64_t*)malloc(sizeof(int64_t) * rows * N);
+  int64_t* z = (int64_t*)calloc(rows * N, sizeof(int64_t));
+  int64_t* lhs = (int64_t*)malloc(sizeof(int64_t) * rows * N);
+  int64_t* rhs = (int64_t*)malloc(sizeof(int64_t) * rows * N);
+  rzko_mat_dot(P->q, N, n + l, k, 1, A, r, ar);
+  memcpy(z + (size_t)n * N, x, sizeof(int64_t) * (size_t)l * N);
+  if (f) {
+    int64_t* zf = (int64_t*)malloc(sizeof(int64_t) * rows * N);
+    rzko_mat_cmul(P->q, N, n + l, 1, c, f, lhs);
+    rzko_mat_cmul(P->q, N, n + l, 1, z, f, zf);
+    rzko_mat_add(P->q, N, n + l, 1, ar, zf, rhs);
+    free(zf);
+  } else {
+    rzko_mat_add(P->q, N, n + l, 1, ar, z, lhs);
+    memcpy(rhs, c, sizeof(int64_t) * rows * N);
+  }
+  const int ok = memcmp(lhs, rhs, sizeof(int64_t) * rows * N) == 0;
+  free(ar);
+  free(z);
+  free(lhs);
+  free(rhs);
   return ok;
 }
 

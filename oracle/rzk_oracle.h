@@ -93,6 +93,9 @@ int rzko_commit(const rzko_params* P, const int64_t* A, const int64_t* x, const 
 /* Commitment::verify with f = None (commit.rs:173-210) */
 int rzko_commitment_verify(const rzko_params* P, const int64_t* A, const int64_t* c,
                            const int64_t* x, const int64_t* r);
+/* commit.rs:173-210 with the optional scalar f (NULL = None) */
+int rzko_commitment_verify_f(const rzko_params* P, const int64_t* A, const int64_t* c,
+                             const int64_t* x, const int64_t* r, const int64_t* f);
 
 /* ---- OpenProof (src/prove/open.rs) ------------------------------------------------------------ */
 /* commit (open.rs:80-103): c = commit(x; r), t = a1.y.  t: n polys.  Returns constraint(r). */

@@ -45,6 +45,8 @@ SIGNATURES = {
     "rzk_ntt_prime": (C.c_uint32, [C.c_int]),
     "rzk_ntt_psi": (C.c_uint32, [C.c_int, C.c_uint32]),
     "rzk_ntt_layout_index": (C.c_uint32, [C.c_uint32, C.c_uint32]),
+    "rzk_commit_batch": (C.c_int, [_CTX, _I64, _I64, _I64, _U8, _SZ]),
+    "rzk_commitment_verify_batch": (C.c_int, [_CTX, _I64, _I64, _I64, _I64, _U8, _SZ]),
     "rzk_open_commit_batch": (C.c_int, [_CTX, _I64, _I64, _I64, _I64, _I64, _U8, _SZ]),
     "rzk_open_response_batch": (C.c_int, [_CTX, _I64, _I64, _I64, _I64, _SZ]),
     "rzk_open_verify_batch": (C.c_int, [_CTX, _I64, _I64, _I64, _I64, _U8, _SZ]),

@@ -248,6 +248,31 @@ class Context:
         self._check(self._L.rzk_prof_read(self._h, C.byref(us), C.byref(cnt)))
         return us.value, cnt.value
 
+    # ---- commitment scheme (src/commit.rs) --------------------------------------------------------------------
+    def commit(self, x, r):
+        """CommitmentKey::commit (commit.rs:88-128) with caller-supplied r: (c, ok)."""
+        B = self._shape(x, self.l, self.N)
+        if self._shape(r, self.k, self.N) != B:
+            raise ValueError("commit: batch / shape mismatch (commit.rs:95)")
+        lead = tuple(x.shape[:-2])
+        c = self._empty(x, lead + (self.n + self.l, self.N))
+        ok = self._empty(x, (B,), np.uint8)
+        dev, p = self._prep([x, r, c, ok], [np.int64] * 3 + [np.uint8])
+        self._check(self._fn("rzk_commit_batch", dev)(self._h, *p, B))
+        return c, ok
+
+    def commitment_verify(self, c, x, r, f=None):
+        """Commitment::verify (commit.rs:173-210); f = None or one scalar polynomial per opening."""
+        B = self._shape(c, self.n + self.l, self.N)
+        if self._shape(x, self.l, self.N) != B or self._shape(r, self.k, self.N) != B:
+            raise ValueError("commitment_verify: batch / shape mismatch")
+        if f is not None and self._shape(f, self.N) != B:
+            raise ValueError("commitment_verify: one f per opening")
+        ok = self._empty(c, (B,), np.uint8)
+        dev, p = self._prep([c, x, r, f, ok], [np.int64] * 4 + [np.uint8])
+        self._check(self._fn("rzk_commitment_verify_batch", dev)(self._h, *p, B))
+        return ok
+
     # ---- OpenProof (src/prove/open.rs) -----------------------------------------------------------------------
     def open_commit(self, x, r, y):
         B = self._shape(x, self.l, self.N)

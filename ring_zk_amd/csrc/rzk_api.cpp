@@ -39,6 +39,8 @@ enum ProgId : int {
   PG_SUM_U,           // variant = V
   PG_SUM_W2,          // variant = V
   PG_SUM_V3,          // variant = V
+  PG_COMMIT,          // c = [a1;a2].r + [0;x]                       (commit.rs:88-128)
+  PG_COMMIT_VERIFY,   // variant bit 1: opening has a scalar f       (commit.rs:173-210)
 };
 
 struct DevProg {
@@ -300,6 +302,32 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
         key_row(c, pb, +1, i, 2, 0);
       }
       if (var & 1) {   // fused check_commit_constraint(r)  (commit.rs:98-107)
+        if (!mark_checks(pb, 1, k)) return RZK_E_UNSUPPORTED;
+      }
+      break;
+    case PG_COMMIT:   // ops: 0 = x[l], 1 = r[k], 2 = c[n+l]
+      for (uint32_t i = 0; i < n + l; ++i) {   // commit.rs:109-125
+        pb.begin_row(2, i, MODE_STORE);
+        key_row(c, pb, +1, i, 1, 0);
+        if (i >= n) pb.add(+1, 0, i - n);
+      }
+      if (var & 1) {   // fused check_commit_constraint(r)  (commit.rs:98-107)
+        if (!mark_checks(pb, 1, k)) return RZK_E_UNSUPPORTED;
+      }
+      break;
+    case PG_COMMIT_VERIFY:   // ops: 0 = x[l], 1 = r[k], 2 = c[n+l], 3 = f ; flags &= (commit.rs:199-209)
+      for (uint32_t i = 0; i < n + l; ++i) {
+        pb.begin_row(0, 0, MODE_ZERO);
+        key_row(c, pb, +1, i, 1, 0);
+        if (var & 2) {   // a.r + z(.)f - c(.)f == 0
+          if (i >= n) pb.vec_term(+1, 0, i - n, 3, 0);
+          pb.vec_term(-1, 2, i, 3, 0);
+        } else {         // a.r + z - c == 0
+          if (i >= n) pb.add(+1, 0, i - n);
+          pb.add(-1, 2, i);
+        }
+      }
+      if (var & 1) {   // fused check_commit_constraint(r)  (commit.rs:183-185)
         if (!mark_checks(pb, 1, k)) return RZK_E_UNSUPPORTED;
       }
       break;
@@ -993,6 +1021,33 @@ uint32_t rzk_ntt_layout_index(uint32_t N, uint32_t j) {
 }
 
 // =================================================================================================
+// Commitment scheme
+// =================================================================================================
+int rzk_commit_batch_dev(rzk_ctx* c, const int64_t* x, const int64_t* r, int64_t* cm, uint8_t* ok, size_t B) {
+  if (!c || !x || !r || !cm) return RZK_E_ARG;
+  const std::vector<OpSpec> specs = {{x, c->l, 0}, {r, c->k, 0}, {cm, c->n + c->l, 0}};
+  int rc = run_program_checked(c, PG_COMMIT, 0, specs, ok, 1, B, B, c->commit_bound);
+  if (rc != RZK_E_UNSUPPORTED) return rc;
+  rc = run_program(c, PG_COMMIT, 0, specs, nullptr, 1, B);
+  if (rc != RZK_OK) return rc;
+  if (ok) rc = run_norm(c, r, c->k, c->commit_bound, ok, B, 0, 0);
+  return rc;
+}
+
+int rzk_commitment_verify_batch_dev(rzk_ctx* c, const int64_t* cm, const int64_t* x, const int64_t* r,
+                                    const int64_t* f, uint8_t* ok, size_t B) {
+  if (!c || !cm || !x || !r || !ok) return RZK_E_ARG;
+  const uint32_t var = f ? 2u : 0u;
+  const std::vector<OpSpec> specs = {{x, c->l, 0}, {r, c->k, 0}, {cm, c->n + c->l, 0}, {f, 1, 0}};
+  // commit.rs:183-185: the norm predicate on r rides on the rows that load r
+  int rc = run_program_checked(c, PG_COMMIT_VERIFY, var, specs, ok, 1, B, B, c->commit_bound);
+  if (rc != RZK_E_UNSUPPORTED) return rc;
+  rc = run_norm(c, r, c->k, c->commit_bound, ok, B, 0, 0);
+  if (rc != RZK_OK) return rc;
+  return run_program(c, PG_COMMIT_VERIFY, var, specs, ok, 1, B);
+}
+
+// =================================================================================================
 // OpenProof
 // =================================================================================================
 int rzk_open_commit_batch_dev(rzk_ctx* c, const int64_t* x, const int64_t* r, const int64_t* y, int64_t* cm,
@@ -1246,6 +1301,23 @@ int rzk_ntt_inverse_batch(rzk_ctx* c, int prime, const uint32_t* in, uint32_t* o
   const size_t bytes = count * c->N * sizeof(uint32_t);
   std::vector<HostBuf> bufs = {IN(in, bytes), OUT(out, bytes)};
   HOST_WRAP(rzk_ntt_inverse_batch_dev(c, prime, DEV(0, const uint32_t*), DEV(1, uint32_t*), count));
+}
+
+int rzk_commit_batch(rzk_ctx* c, const int64_t* x, const int64_t* r, int64_t* cm, uint8_t* ok, size_t B) {
+  if (!c || !x || !r || !cm) return RZK_E_ARG;
+  std::vector<HostBuf> bufs = {IN(x, polys(c, B * c->l)), IN(r, polys(c, B * c->k)),
+                               OUT(cm, polys(c, B * (c->n + c->l))), OUT(ok, ok ? B : 0)};
+  HOST_WRAP(rzk_commit_batch_dev(c, DEV(0, const int64_t*), DEV(1, const int64_t*), DEV(2, int64_t*),
+                                 ok ? DEV(3, uint8_t*) : nullptr, B));
+}
+
+int rzk_commitment_verify_batch(rzk_ctx* c, const int64_t* cm, const int64_t* x, const int64_t* r, const int64_t* f,
+                                uint8_t* ok, size_t B) {
+  if (!c || !cm || !x || !r || !ok) return RZK_E_ARG;
+  std::vector<HostBuf> bufs = {IN(cm, polys(c, B * (c->n + c->l))), IN(x, polys(c, B * c->l)),
+                               IN(r, polys(c, B * c->k)), IN(f, f ? polys(c, B) : 0), OUT(ok, B)};
+  HOST_WRAP(rzk_commitment_verify_batch_dev(c, DEV(0, const int64_t*), DEV(1, const int64_t*), DEV(2, const int64_t*),
+                                            f ? DEV(3, const int64_t*) : nullptr, DEV(4, uint8_t*), B));
 }
 
 int rzk_open_commit_batch(rzk_ctx* c, const int64_t* x, const int64_t* r, const int64_t* y, int64_t* cm, int64_t* t,

@@ -116,7 +116,8 @@ Poly random_polynomial_from_challenge_set(Rng& rng, size_t kappa) {   // challen
 // ---- commitment scheme (src/commit.rs) ----------------------------------------------------------------------
 template <size_t N>
 struct Opening {
-  PolyVec x, r;   // f is always None when produced by the crate (commit.rs:127)
+  PolyVec x, r;
+  Poly f;         // empty = None (what CommitmentKey::commit produces, commit.rs:127); else the scalar of a relaxed opening
 };
 
 template <size_t N>
@@ -146,22 +147,20 @@ class CommitmentKey {
   std::pair<Opening<N>, PolyVec> commit(Rng& rng, const PolyVec& x) const {
     const Params& P = be_->params;
     if (x.size() != P.l) throw std::runtime_error("commit: x.len() != l (commit.rs:95)");
-    std::vector<int64_t> xf, zf((P.n + P.l) * N, 0), cf((P.n + P.l) * N);
+    std::vector<int64_t> xf, cf((P.n + P.l) * N);
     flatten(x, N, xf);
-    std::copy(xf.begin(), xf.end(), zf.begin() + P.n * N);   // z = [0_n ; x] (commit.rs:116-121)
     PolyVec r;
     std::vector<int64_t> rf;
-    for (;;) {
+    for (;;) {   // commit.rs:98-107: resample r until the constraint holds; the product rides along
       r.clear();
       for (size_t i = 0; i < P.k; ++i) r.push_back(random_polynomial_within<N>(rng, (int64_t)P.b));
       rf.clear();
       flatten(r, N, rf);
       uint8_t ok = 0;
-      be_->check(rzk_norm2_le_batch(be_->ctx(), rf.data(), (uint32_t)P.k, rzk_commit_bound(be_->ctx()), &ok, 1));
+      be_->check(rzk_commit_batch(be_->ctx(), xf.data(), rf.data(), cf.data(), &ok, 1));   // a.dot(&r).add(&z)
       if (ok) break;
     }
-    be_->check(rzk_matvec_batch(be_->ctx(), RZK_KEY_A, rf.data(), zf.data(), cf.data(), 1));   // a.dot(&r).add(&z)
-    return {Opening<N>{x, r}, unflatten(cf, N)};
+    return {Opening<N>{x, r, {}}, unflatten(cf, N)};
   }
   const std::shared_ptr<Backend<N>>& backend() const { return be_; }
   PolyVec a;   // (n+l)*k polynomials, row-major
@@ -170,22 +169,19 @@ class CommitmentKey {
   std::shared_ptr<Backend<N>> be_;
 };
 
-// Commitment::verify with f = None (commit.rs:173-210)
+// Commitment::verify (commit.rs:173-210), both branches of the optional scalar f
 template <size_t N>
 bool commitment_verify(const PolyVec& c, const Opening<N>& o, const CommitmentKey<N>& ck) {
   const auto& be = ck.backend();
-  const Params& P = be->params;
-  std::vector<int64_t> rf, xf, zf((P.n + P.l) * N, 0), cf, got((P.n + P.l) * N);
+  std::vector<int64_t> rf, xf, cf;
   flatten(o.r, N, rf);
   flatten(o.x, N, xf);
   flatten(c, N, cf);
-  uint8_t ok = 0, eq = 0;
-  be->check(rzk_norm2_le_batch(be->ctx(), rf.data(), (uint32_t)P.k, rzk_commit_bound(be->ctx()), &ok, 1));
-  if (!ok) return false;
-  std::copy(xf.begin(), xf.end(), zf.begin() + P.n * N);
-  be->check(rzk_matvec_batch(be->ctx(), RZK_KEY_A, rf.data(), zf.data(), got.data(), 1));
-  be->check(rzk_eq_batch(be->ctx(), got.data(), cf.data(), (uint32_t)(P.n + P.l), &eq, 1));
-  return eq != 0;
+  Poly f = o.f;
+  if (!f.empty()) f.resize(N, 0);   // trimmed representation -> dense
+  uint8_t ok = 0;
+  be->check(rzk_commitment_verify_batch(be->ctx(), cf.data(), xf.data(), rf.data(), f.empty() ? nullptr : f.data(), &ok, 1));
+  return ok != 0;
 }
 
 // ---- OpenProof (src/prove/open.rs) ----------------------------------------------------------------------------

@@ -54,6 +54,13 @@ static void test_open_proof(int iters) {
       Opening<N> wrong = rctx.opening;          // commit.rs:169-170: mismatched opening is rejected
       wrong.x[0][0] += wrong.x[0][0] > 0 ? -1 : 1;
       REQUIRE(!commitment_verify(cm.c, wrong, ck));
+      // relaxed opening (commit.rs:199-206): f*c == a.(f*r) + f*[0;x] with f = 2 and r' = 2r
+      Opening<N> relaxed = rctx.opening;
+      relaxed.f = Poly{2};
+      REQUIRE(!commitment_verify(cm.c, relaxed, ck));   // r not scaled yet
+      for (auto& poly : relaxed.r)
+        for (auto& coef : poly) coef *= 2;
+      REQUIRE(commitment_verify(cm.c, relaxed, ck));
     }
   }
   std::printf("test_open_proof ok (%d iterations, N=%zu)\n", iters, N);

@@ -460,3 +460,57 @@ def test_challenge_products_any_multiplier(torch_mod, N):
     assert acc.tolist() == [1, 1, 0, 1, 0, 1]
     for b in range(B):
         assert int(acc[b]) == int(O.open_verify(P, A, zs[b], t[b], c[b], d[b]) == 1)
+
+
+# ---- commitment scheme (src/commit.rs) ------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(512, 1, 3, 1), (1024, 1, 3, 1), (512, 2, 5, 2)])
+def test_commit_and_commitment_verify(torch_mod, shape):
+    """CommitmentKey::commit and Commitment::verify incl. the f = Some(_) branch (commit.rs:88-128, 173-210);
+    mirrors the reference's doctest (commit.rs:152-171): a fresh commitment verifies, a wrong message or
+    wrong randomness does not."""
+    N, n, k, l = shape
+    ctx = ctx_for(N, n, k, l)
+    P = _P(ctx)
+    rng = np.random.default_rng(4242 + sum(shape))
+    A = synth.key(rng, N, n, k, l)
+    ctx.load_key(A)
+    B = 6
+    x = synth.uniform(rng, (B, l, N))
+    r = synth.small(rng, (B, k, N))
+    r[4] = synth.uniform(rng, (k, N))                       # violates the commit constraint
+    c, ok = ctx.commit(x, r)
+    for b in range(B):
+        c_ref, ok_ref = O.commit(P, A, x[b], r[b])
+        assert np.array_equal(c[b], c_ref) and bool(ok[b]) == ok_ref
+    assert ok.tolist() == [1, 1, 1, 1, 0, 1]
+    # f = None
+    x_bad = x.copy()
+    x_bad[1, 0, 3] = O.center(int(x_bad[1, 0, 3]) + 1)      # wrong message
+    r_bad = r.copy()
+    r_bad[2, k - 1, 0] = O.center(int(r_bad[2, k - 1, 0]) + 1)   # wrong randomness (still small)
+    for xs, rs in ((x, r), (x_bad, r), (x, r_bad)):
+        got = ctx.commitment_verify(c, xs, rs)
+        want = [int(O.commitment_verify(P, A, c[b], xs[b], rs[b])) for b in range(B)]
+        assert got.tolist() == want
+    assert ctx.commitment_verify(c, x, r).tolist() == [1, 1, 1, 1, 0, 1]
+    assert ctx.commitment_verify(c, x_bad, r).tolist() == [1, 0, 1, 1, 0, 1]
+    # f = Some(f): f * c == a.r' + f * [0;x] holds for r' = f * r; use a small f so that r' stays short
+    f = np.zeros((B, N), dtype=np.int64)
+    f[:, 0] = 2
+    f[3, 5] = -1
+    rf = np.stack([O.mat_cmul(r[b][:, None, :], f[b])[:, 0, :] for b in range(B)])
+    got = ctx.commitment_verify(c, x, rf, f)
+    want = [int(O.commitment_verify(P, A, c[b], x[b], rf[b], f[b])) for b in range(B)]
+    assert got.tolist() == want and got.tolist()[:4] == [1, 1, 1, 1] and got.tolist()[4] == 0
+    got = ctx.commitment_verify(c, x_bad, rf, f)
+    want = [int(O.commitment_verify(P, A, c[b], x_bad[b], rf[b], f[b])) for b in range(B)]
+    assert got.tolist() == want and got.tolist()[1] == 0
+    ff = synth.uniform(rng, (B, N))                          # full-range f with the unscaled r: must reject
+    got = ctx.commitment_verify(c, x, r, ff)
+    want = [int(O.commitment_verify(P, A, c[b], x[b], r[b], ff[b])) for b in range(B)]
+    assert got.tolist() == want
+    # device pointers: identical results
+    gd = ctx.commitment_verify(dev(torch_mod, c), dev(torch_mod, x), dev(torch_mod, rf), dev(torch_mod, f))
+    assert gd.cpu().numpy().tolist() == ctx.commitment_verify(c, x, rf, f).tolist()
+    cd, okd = ctx.commit(dev(torch_mod, x), dev(torch_mod, r))
+    assert np.array_equal(cd.cpu().numpy(), c) and np.array_equal(okd.cpu().numpy(), ok)

@@ -163,3 +163,31 @@ def test_oracle_ntt_roundtrip_and_convolution():
                     ref[t - N] = (ref[t - N] - v) % p
         if N <= 8:
             assert [int(v) for v in c] == ref
+
+
+def test_commitment_verify_with_scalar_f():
+    """Commitment::verify, f = Some(_) branch (commit.rs:199-206): f*c == a.(f*r) + f*[0;x] for every f,
+    and the f = None form is the special case f = 1."""
+    N, n, k, l = 16, 1, 3, 1
+    P = O.Params(N, n, k, l)
+    rng = np.random.default_rng(31)
+    half = (O.Q_DEFAULT - 1) // 2
+    A = O.key_build(P, rng.integers(-half, half + 1, (n, k - n, N)), rng.integers(-half, half + 1, (l, k - n - l, N)))
+    x = rng.integers(-half, half + 1, (l, N))
+    r = rng.integers(-1, 2, (k, N))
+    c, ok = O.commit(P, A, x, r)
+    assert ok and O.commitment_verify(P, A, c, x, r)
+    one = np.zeros(N, dtype=np.int64)
+    one[0] = 1
+    assert O.commitment_verify(P, A, c, x, r, one)
+    f = np.zeros(N, dtype=np.int64)
+    f[0], f[3] = 2, -1
+    rf = O.mat_cmul(r[:, None, :], f)[:, 0, :]
+    assert O.commitment_verify(P, A, c, x, rf, f)
+    assert not O.commitment_verify(P, A, c, x, r, f)         # r not scaled by f
+    x2 = x.copy()
+    x2[0, 1] = O.center(int(x2[0, 1]) + 1)
+    assert not O.commitment_verify(P, A, c, x2, rf, f)
+    big = rng.integers(-half, half + 1, (k, N))              # norm constraint on r comes first (commit.rs:183-185)
+    cb, okb = O.commit(P, A, x, big)
+    assert not okb and not O.commitment_verify(P, A, cb, x, big) and not O.commitment_verify(P, A, cb, x, big, one)

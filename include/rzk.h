@@ -212,6 +212,25 @@ int rzk_sum_verify_batch_dev(rzk_ctx* ctx, uint32_t V, const int64_t* zs, const 
  * returns the average kernel duration in microseconds (negative status on error). */
 double rzk_bench_ntt_forward_dev(rzk_ctx* ctx, int prime, const uint32_t* in, uint32_t* out,
                                  size_t count, int iters);
+/* ---- wire format (host only) ---------------------------------------------------------------------------- */
+/* bincode layout of the reference's Mat<I,N> (serde derive at src/mat.rs:11-14; bincode default options as in
+ * the reference's own test src/mat.rs:424-438: little-endian, u64 length prefixes):
+ *     u64 rows ; rows x { u64 cols ; cols x { u64 len ; len x coefficient } }
+ * with every polynomial in the crate's trimmed form (no trailing zero coefficients) <-> dense slabs
+ * [rows][cols][N] of int64.  The protocol messages (src/commit.rs:134, src/prove/open.rs:180-228, ...) are
+ * plain concatenations of their Mat fields in declaration order.  coef_bytes: 8 (i64) or 4 (i32, the width
+ * of the reference's test vector); the width ZqI64 uses on the wire is set by the third-party ring crate and
+ * is not pinned by any file of the reference.
+ * encode: writes rzk_wire_mat_size() bytes (returned through *written; RZK_E_ARG if cap is too small or a
+ *         coefficient does not fit coef_bytes).
+ * decode: slab may be NULL to measure only; fails on ragged rows, polynomials longer than N, or truncated
+ *         input; *consumed = bytes read, so consecutive fields of a message can be decoded in turn. */
+size_t rzk_wire_mat_size(const int64_t* slab, uint32_t rows, uint32_t cols, uint32_t N, uint32_t coef_bytes);
+int rzk_wire_mat_encode(const int64_t* slab, uint32_t rows, uint32_t cols, uint32_t N, uint32_t coef_bytes,
+                        uint8_t* out, size_t cap, size_t* written);
+int rzk_wire_mat_decode(const uint8_t* in, size_t len, uint32_t N, uint32_t coef_bytes, uint32_t* rows,
+                        uint32_t* cols, int64_t* slab, size_t slab_polys, size_t* consumed);
+
 /* HIP-event timing of the last phase call's dominant kernel is exposed through these counters:
  * accumulated microseconds and launch count of the row kernel since the last reset. */
 int rzk_prof_reset(rzk_ctx* ctx);

@@ -56,6 +56,11 @@ SIGNATURES = {
     "rzk_sum_commit_batch": (C.c_int, [_CTX, C.c_uint32] + [_I64] * 11 + [_U8, _SZ]),
     "rzk_sum_response_batch": (C.c_int, [_CTX, C.c_uint32] + [_I64] * 7 + [_SZ]),
     "rzk_sum_verify_batch": (C.c_int, [_CTX, C.c_uint32] + [_I64] * 9 + [_U8, _SZ]),
+    "rzk_wire_mat_size": (C.c_size_t, [_I64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "rzk_wire_mat_encode": (C.c_int, [_I64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _U8, _SZ,
+                                      C.POINTER(C.c_size_t)]),
+    "rzk_wire_mat_decode": (C.c_int, [_U8, _SZ, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                      _I64, _SZ, C.POINTER(C.c_size_t)]),
     "rzk_bench_ntt_forward_dev": (C.c_double, [_CTX, C.c_int, _U32P, _U32P, _SZ, C.c_int]),
     "rzk_prof_reset": (C.c_int, [_CTX]),
     "rzk_prof_enable": (C.c_int, [_CTX, C.c_int]),

@@ -8,7 +8,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "librzk_hip.so")
-SOURCES = ["rzk_kernels.hip", "rzk_api.cpp"]
+SOURCES = ["rzk_kernels.hip", "rzk_api.cpp", "rzk_wire.cpp"]
 HEADERS = ["rzk_core.h", "rzk_dev.h", "rzk_tables.h"]
 ARCH = "gfx950"
 

@@ -236,6 +236,10 @@ int rzk_wire_mat_decode(const uint8_t* in, size_t len, uint32_t N, uint32_t coef
 int rzk_prof_reset(rzk_ctx* ctx);
 int rzk_prof_enable(rzk_ctx* ctx, int on);
 int rzk_prof_read(rzk_ctx* ctx, double* row_kernel_us, uint64_t* row_kernel_launches);
+/* launches recorded since the last reset / read (host counter, no synchronisation), and their individual
+ * durations in launch order (synchronises; does not clear) */
+uint64_t rzk_prof_count(const rzk_ctx* ctx);
+int rzk_prof_read_all(rzk_ctx* ctx, double* us, size_t cap, size_t* count);
 
 #ifdef __cplusplus
 }

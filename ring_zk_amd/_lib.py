@@ -65,6 +65,8 @@ SIGNATURES = {
     "rzk_prof_reset": (C.c_int, [_CTX]),
     "rzk_prof_enable": (C.c_int, [_CTX, C.c_int]),
     "rzk_prof_read": (C.c_int, [_CTX, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "rzk_prof_count": (C.c_uint64, [_CTX]),
+    "rzk_prof_read_all": (C.c_int, [_CTX, C.POINTER(C.c_double), _SZ, C.POINTER(C.c_size_t)]),
 }
 # every batched entry point also exists as a device-pointer variant with the same signature
 for _name in list(SIGNATURES):

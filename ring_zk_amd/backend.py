@@ -248,6 +248,18 @@ class Context:
         self._check(self._L.rzk_prof_read(self._h, C.byref(us), C.byref(cnt)))
         return us.value, cnt.value
 
+    def prof_count(self) -> int:
+        """Launches recorded so far (no synchronisation)."""
+        return int(self._L.rzk_prof_count(self._h))
+
+    def prof_read_all(self):
+        """Durations (us) of the recorded launches, in launch order."""
+        n = self.prof_count()
+        buf = (C.c_double * max(n, 1))()
+        cnt = C.c_size_t(0)
+        self._check(self._L.rzk_prof_read_all(self._h, buf, n, C.byref(cnt)))
+        return [buf[i] for i in range(min(n, cnt.value))]
+
     # ---- commitment scheme (src/commit.rs) --------------------------------------------------------------------
     def commit(self, x, r):
         """CommitmentKey::commit (commit.rs:88-128) with caller-supplied r: (c, ok)."""

@@ -9,7 +9,7 @@ out=gpurun_out/ab_env.jsonl
 for rep in 1 2 3; do
   for cfg in "$@"; do
     if [ "$cfg" = "-" ]; then envs=""; else envs="$cfg"; fi
-    line=$(env $envs python bench.py --steps 30 --warmup 5 --no-cpu-baseline ${BENCH_ARGS:-} 2>/dev/null | tail -1)
+    line=$(env $envs python bench.py --steps 200 --warmup 100 --no-cpu-baseline ${BENCH_ARGS:-} 2>/dev/null | tail -1)
     echo "{\"cfg\": \"$cfg\", \"rep\": $rep, \"bench\": $line}" >> $out
   done
 done

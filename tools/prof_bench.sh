@@ -4,7 +4,7 @@
 tag=$1; shift
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_$tag -o $tag -- python3 $root/bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" > $root/gpurun_out/prof_$tag.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $root/gpurun_out/prof_$tag -o $tag -- python3 $root/bench.py --steps 200 --warmup 100 --no-cpu-baseline "$@" > $root/gpurun_out/prof_$tag.log 2>&1
 cd $root
 f=$(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1)
 python3 - "$f" <<'PY'

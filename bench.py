@@ -131,13 +131,27 @@ def main():
     gk.manual_seed(1234)
     A = synth.t_key(gk, N, n, k, l, dev)
     ctx.load_key(A)
-    g = torch.Generator(device=dev)
-    g.manual_seed(1000 + rank)
-    d = synth.t_challenge(g, B, N, ctx.kappa, dev)
+    # per-proof inputs from the library's device-side samplers (counter-based, seed recorded in the output):
+    # the reference's distributions: x, g uniform over Z_q; r uniform in [-b, b]; y = (i64) N(0, sigma);
+    # d with kappa coefficients +-1
+    seed = 1000 + rank
+    half = (ctx.q - 1) // 2
+    sid = iter(range(64))
+
+    def uni(*lead):
+        return ctx.sample_uniform(seed, next(sid), half, lead)
+
+    def small(*lead):
+        return ctx.sample_uniform(seed, next(sid), ctx.b, lead)
+
+    def gauss(*lead):
+        return ctx.sample_gauss(seed, next(sid), float(sig), lead)
+
+    d = ctx.sample_challenge(seed, next(sid), (B,))
     if args.workload == "open":
-        x = synth.t_uniform(g, (B, l, N), dev)
-        r = synth.t_small(g, (B, k, N), dev)
-        y = synth.t_gauss(g, (B, k, N), dev, sig)
+        x = uni(B, l)
+        r = small(B, k)
+        y = gauss(B, k)
         cycle_polys = (l + 2 * k) + (2 * n + l) + (2 * k + 1) + k + (k + 2 * n + 1)   # 26 at (1,3,1): SURVEY §8d
         row_launches = 3
 
@@ -150,10 +164,10 @@ def main():
             yield "verify"
             phases.result = (ok, acc)
     elif args.workload == "linear":
-        gp = synth.t_uniform(g, (B, N), dev)
-        x = synth.t_uniform(g, (B, l, N), dev)
-        r, rp = synth.t_small(g, (B, k, N), dev), synth.t_small(g, (B, k, N), dev)
-        y, yp = synth.t_gauss(g, (B, k, N), dev, sig), synth.t_gauss(g, (B, k, N), dev, sig)
+        gp = uni(B)
+        x = uni(B, l)
+        r, rp = small(B, k), small(B, k)
+        y, yp = gauss(B, k), gauss(B, k)
         cycle_polys = ((1 + l + 4 * k) + (4 * n + 3 * l)) + ((4 * k + 1) + 2 * k) + (2 * k + 2 * (n + l) + 1 + 2 * n + l + 1)
         row_launches = 3 + 1 + 2
 
@@ -166,10 +180,10 @@ def main():
             yield "verify"
             phases.result = ((ok == 3).to(torch.uint8), acc)
     else:
-        gs = synth.t_uniform(g, (B, V, N), dev)
-        xs = synth.t_uniform(g, (B, V, l, N), dev)
-        rs, rp = synth.t_small(g, (B, V, k, N), dev), synth.t_small(g, (B, k, N), dev)
-        ys, yp = synth.t_gauss(g, (B, V, k, N), dev, sig), synth.t_gauss(g, (B, k, N), dev, sig)
+        gs = uni(B, V)
+        xs = uni(B, V, l)
+        rs, rp = small(B, V, k), small(B, k)
+        ys, yp = gauss(B, V, k), gauss(B, k)
         cycle_polys = ((V + V * l + 2 * V * k + 2 * k) + ((V + 1) * (n + l) + (V + 1) * n + l)) + \
                       ((2 * V * k + 2 * k + 1) + (V + 1) * k) + \
                       ((V + 1) * k + (V + 1) * (n + l) + V + (V + 1) * n + l + 1)
@@ -260,7 +274,8 @@ def main():
             except Exception:
                 traffic = None
         roofline = {
-            "kernel": f"row_kernel<log2 N={N.bit_length() - 1}> ({args.workload} commit / response / verify row programs)",
+            "kernel": f"row-program kernels at log2 N={N.bit_length() - 1} (row_kernel: commit / verify rows; "
+                      "shift_row_kernel: response rows), one launch per phase",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
@@ -305,7 +320,9 @@ def main():
                             + (f"V={V} summands, " if args.workload == "sum" else "") + f"batch={B} proofs per GPU",
                 "arithmetic": "u32 residues of up to three 30-bit NTT primes, exact CRT to the centred residue mod q; "
                               "int64 coefficients at the boundary",
-                "challenge": "pre-sampled (host RNG is outside the path)",
+                "inputs": f"device-side samplers (Philox4x32-10), seed {1000}+rank: x uniform over Z_q, r in [-b,b], "
+                          "y=(i64)N(0,sigma), d with kappa +-1; resident in HBM before the timed region",
+                "challenge": "pre-sampled (sampling is outside the path)",
                 "parallelism": f"batch split over {world} GPU(s), no data-path collective",
                 "accepted": tot_acc,
             },

@@ -212,6 +212,21 @@ int rzk_sum_verify_batch_dev(rzk_ctx* ctx, uint32_t V, const int64_t* zs, const 
  * returns the average kernel duration in microseconds (negative status on error). */
 double rzk_bench_ntt_forward_dev(rzk_ctx* ctx, int prime, const uint32_t* in, uint32_t* out,
                                  size_t count, int iters);
+/* ---- device-side samplers ----------------------------------------------------------------------------------- */
+/* The distributions of the reference's host RNG helpers, drawn in HBM by a counter-based generator
+ * (Philox4x32-10; output = f(seed, stream, polynomial index, position), reproducible and order-independent).
+ * Parity with the reference is statistical, not bit-for-bit (the reference draws from rand's thread RNG).
+ * count = number of polynomials written to out:[count][N].
+ *   uniform   random_polynomial_within (src/polynomial.rs:14-25): coefficients uniform in [-bound, bound],
+ *             1 <= bound <= (q-1)/2  (commit randomness r: bound = b, commit.rs:101; key / message: (q-1)/2)
+ *   gauss     random_polynomial_in_normal_distribution (src/polynomial.rs:28-44): (i64) N(0, sigma), truncated
+ *             toward zero like I::from_f64; y of the provers: sigma = rzk_sigma(ctx) (open.rs:88-94)
+ *   challenge random_polynomial_from_challenge_set (src/challenge_space.rs:12-33): exactly kappa coefficients
+ *             +-1 (kappa of the context) at a uniformly random subset of positions, zeros elsewhere */
+int rzk_sample_uniform_dev(rzk_ctx* ctx, uint64_t seed, uint32_t stream, uint64_t bound, int64_t* out, size_t count);
+int rzk_sample_gauss_dev(rzk_ctx* ctx, uint64_t seed, uint32_t stream, double sigma, int64_t* out, size_t count);
+int rzk_sample_challenge_dev(rzk_ctx* ctx, uint64_t seed, uint32_t stream, int64_t* out, size_t count);
+
 /* ---- wire format (host only) ---------------------------------------------------------------------------- */
 /* bincode layout of the reference's Mat<I,N> (serde derive at src/mat.rs:11-14; bincode default options as in
  * the reference's own test src/mat.rs:424-438: little-endian, u64 length prefixes):

@@ -56,6 +56,9 @@ SIGNATURES = {
     "rzk_sum_commit_batch": (C.c_int, [_CTX, C.c_uint32] + [_I64] * 11 + [_U8, _SZ]),
     "rzk_sum_response_batch": (C.c_int, [_CTX, C.c_uint32] + [_I64] * 7 + [_SZ]),
     "rzk_sum_verify_batch": (C.c_int, [_CTX, C.c_uint32] + [_I64] * 9 + [_U8, _SZ]),
+    "rzk_sample_uniform_dev": (C.c_int, [_CTX, C.c_uint64, C.c_uint32, C.c_uint64, _I64, _SZ]),
+    "rzk_sample_gauss_dev": (C.c_int, [_CTX, C.c_uint64, C.c_uint32, C.c_double, _I64, _SZ]),
+    "rzk_sample_challenge_dev": (C.c_int, [_CTX, C.c_uint64, C.c_uint32, _I64, _SZ]),
     "rzk_wire_mat_size": (C.c_size_t, [_I64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rzk_wire_mat_encode": (C.c_int, [_I64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _U8, _SZ,
                                       C.POINTER(C.c_size_t)]),

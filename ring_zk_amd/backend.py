@@ -260,6 +260,33 @@ class Context:
         self._check(self._L.rzk_prof_read_all(self._h, buf, n, C.byref(cnt)))
         return [buf[i] for i in range(min(n, cnt.value))]
 
+    # ---- device-side samplers (statistical parity with src/polynomial.rs:14-44, src/challenge_space.rs:12-33) ----
+    def _sample_out(self, lead):
+        import torch
+
+        self._bind_torch_stream()
+        shape = tuple(lead) + (self.N,)
+        out = torch.empty(shape, dtype=torch.int64, device=torch.device("cuda", self.device))
+        return out, int(np.prod(shape[:-1], dtype=np.int64))
+
+    def sample_uniform(self, seed: int, stream: int, bound: int, lead):
+        """[*lead][N] coefficients uniform in [-bound, bound] (random_polynomial_within)."""
+        out, cnt = self._sample_out(lead)
+        self._check(self._L.rzk_sample_uniform_dev(self._h, seed, stream, bound, C.c_void_p(out.data_ptr()), cnt))
+        return out
+
+    def sample_gauss(self, seed: int, stream: int, sigma: float, lead):
+        """[*lead][N] coefficients (i64) N(0, sigma) (random_polynomial_in_normal_distribution)."""
+        out, cnt = self._sample_out(lead)
+        self._check(self._L.rzk_sample_gauss_dev(self._h, seed, stream, float(sigma), C.c_void_p(out.data_ptr()), cnt))
+        return out
+
+    def sample_challenge(self, seed: int, stream: int, lead):
+        """[*lead][N] challenges: kappa coefficients +-1 (random_polynomial_from_challenge_set)."""
+        out, cnt = self._sample_out(lead)
+        self._check(self._L.rzk_sample_challenge_dev(self._h, seed, stream, C.c_void_p(out.data_ptr()), cnt))
+        return out
+
     # ---- commitment scheme (src/commit.rs) --------------------------------------------------------------------
     def commit(self, x, r):
         """CommitmentKey::commit (commit.rs:88-128) with caller-supplied r: (c, ok)."""

@@ -1023,6 +1023,23 @@ uint32_t rzk_ntt_layout_index(uint32_t N, uint32_t j) {
 }
 
 // =================================================================================================
+// Device-side samplers
+// =================================================================================================
+int rzk_sample_uniform_dev(rzk_ctx* c, uint64_t seed, uint32_t stream, uint64_t bound, int64_t* out, size_t count) {
+  if (!c || !out || bound == 0 || bound > (uint64_t)(c->q - 1) / 2) return RZK_E_ARG;
+  return check_launch(c, launch_sample_uniform(cfg_of(c), out, count, c->N, seed, stream, (uint32_t)bound), "sampler");
+}
+int rzk_sample_gauss_dev(rzk_ctx* c, uint64_t seed, uint32_t stream, double sigma, int64_t* out, size_t count) {
+  // |x| stays far below (q-1)/2 for every sigma the parameters produce; 2^26 keeps 12 sigma inside the range
+  if (!c || !out || !(sigma > 0.0) || sigma > 67108864.0) return RZK_E_ARG;
+  return check_launch(c, launch_sample_gauss(cfg_of(c), out, count, c->N, seed, stream, sigma), "sampler");
+}
+int rzk_sample_challenge_dev(rzk_ctx* c, uint64_t seed, uint32_t stream, int64_t* out, size_t count) {
+  if (!c || !out) return RZK_E_ARG;
+  return check_launch(c, launch_sample_challenge(cfg_of(c), out, count, c->N, seed, stream, c->kappa), "sampler");
+}
+
+// =================================================================================================
 // Commitment scheme
 // =================================================================================================
 int rzk_commit_batch_dev(rzk_ctx* c, const int64_t* x, const int64_t* r, int64_t* cm, uint8_t* ok, size_t B) {

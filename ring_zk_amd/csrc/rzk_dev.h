@@ -131,6 +131,13 @@ int launch_key_transform(int logn, const LaunchCfg& cfg, const int64_t* d_key, u
 int launch_ntt(int logn, bool inverse, const LaunchCfg& cfg, int prime, const uint32_t* d_in,
                uint32_t* d_out, uint64_t count, const DevTables* d_T, const uint32_t* d_tw);
 int launch_fill_u8(const LaunchCfg& cfg, uint8_t* p, uint8_t value, uint64_t n);
+// device-side samplers (rzk_rng.h): npoly polynomials of n_ring coefficients each
+int launch_sample_uniform(const LaunchCfg& cfg, int64_t* out, uint64_t npoly, uint32_t n_ring, uint64_t seed,
+                          uint32_t stream, uint32_t bound);
+int launch_sample_gauss(const LaunchCfg& cfg, int64_t* out, uint64_t npoly, uint32_t n_ring, uint64_t seed,
+                        uint32_t stream, double sigma);
+int launch_sample_challenge(const LaunchCfg& cfg, int64_t* out, uint64_t npoly, uint32_t n_ring, uint64_t seed,
+                            uint32_t stream, uint32_t kappa);
 int launch_addsub(const LaunchCfg& cfg, bool sub, const int64_t* a, const int64_t* b, int64_t* out,
                   uint64_t ncoef, const DevTables* d_T);
 // ok[b] = (all `rows` polys of proof b have sum c^2 < limit), limit = (bound+1)^2 given as hi:lo.

@@ -11,6 +11,7 @@
 
 #include "rzk_core.h"
 #include "rzk_dev.h"
+#include "rzk_rng.h"
 
 namespace rzk {
 
@@ -1254,6 +1255,92 @@ eq_kernel_small(const int64_t* __restrict__ a, const int64_t* __restrict__ b, ui
 }
 
 // =============================================================================================
+// Device-side samplers: the distributions of the reference's host RNG helpers, drawn with a
+// counter-based generator (rzk_rng.h).  One thread draws 4 coefficients from one Philox block (two blocks for
+// the wide uniform range), so a polynomial is N/4 independent units and any number of polynomials fills the chip.
+//   uniform   random_polynomial_within (src/polynomial.rs:14-25): every coefficient uniform in [-bound, bound]
+//   gauss     random_polynomial_in_normal_distribution (polynomial.rs:28-44): (i64) N(0, sigma), i.e. truncated
+//             toward zero as I::from_f64 does
+//   challenge random_polynomial_from_challenge_set (src/challenge_space.rs:12-33): kappa coefficients +-1 at a
+//             uniformly random kappa-subset of the N positions (what shuffling kappa marked slots gives)
+// =============================================================================================
+__global__ void __launch_bounds__(256)
+sample_uniform_kernel(int64_t* __restrict__ out, uint64_t ncoef, uint32_t n_ring, uint64_t seed, uint32_t stream,
+                      uint32_t bound) {
+  const uint32_t range = 2u * bound + 1u;   // bound <= (2^32 - 2) / 2
+  for (uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x; u * 4 < ncoef; u += (uint64_t)gridDim.x * 256) {
+    const uint64_t c0 = u * 4;
+    const uint64_t poly = c0 / n_ring;
+    const uint32_t blk = (uint32_t)((c0 - poly * n_ring) / 4);
+    const Philox4 a = sampler_block(seed, stream, poly, 2 * blk), b = sampler_block(seed, stream, poly, 2 * blk + 1);
+    int64_t v[4];
+    v[0] = (int64_t)uniform_below(a.v[0], a.v[1], range) - (int64_t)bound;
+    v[1] = (int64_t)uniform_below(a.v[2], a.v[3], range) - (int64_t)bound;
+    v[2] = (int64_t)uniform_below(b.v[0], b.v[1], range) - (int64_t)bound;
+    v[3] = (int64_t)uniform_below(b.v[2], b.v[3], range) - (int64_t)bound;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (c0 + i < ncoef) out[c0 + i] = v[i];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+sample_gauss_kernel(int64_t* __restrict__ out, uint64_t ncoef, uint32_t n_ring, uint64_t seed, uint32_t stream,
+                    double sigma) {
+  for (uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x; u * 4 < ncoef; u += (uint64_t)gridDim.x * 256) {
+    const uint64_t c0 = u * 4;
+    const uint64_t poly = c0 / n_ring;
+    const uint32_t blk = (uint32_t)((c0 - poly * n_ring) / 4);
+    const Philox4 a = sampler_block(seed, stream, poly, 2 * blk), b = sampler_block(seed, stream, poly, 2 * blk + 1);
+    // two Box-Muller pairs from 53-bit uniforms in (0,1]
+    const double k = 1.0 / 9007199254740992.0;   // 2^-53
+    const double u0 = ((double)((((uint64_t)a.v[0] << 32) | a.v[1]) >> 11) + 1.0) * k;
+    const double u1 = (double)((((uint64_t)a.v[2] << 32) | a.v[3]) >> 11) * k;
+    const double u2 = ((double)((((uint64_t)b.v[0] << 32) | b.v[1]) >> 11) + 1.0) * k;
+    const double u3 = (double)((((uint64_t)b.v[2] << 32) | b.v[3]) >> 11) * k;
+    const double r0 = sigma * sqrt(-2.0 * log(u0)), r1 = sigma * sqrt(-2.0 * log(u2));
+    double s0, c0d, s1, c1d;
+    sincospi(2.0 * u1, &s0, &c0d);
+    sincospi(2.0 * u3, &s1, &c1d);
+    const double g[4] = {r0 * c0d, r0 * s0, r1 * c1d, r1 * s1};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (c0 + i < ncoef) out[c0 + i] = (int64_t)g[i];   // conversion truncates toward zero, like I::from_f64
+  }
+}
+
+// one wavefront per polynomial: lane 0 picks the kappa-subset (Floyd's algorithm on an LDS bitmap-like byte map),
+// then all lanes write the N coefficients
+__global__ void __launch_bounds__(256)
+sample_challenge_kernel(int64_t* __restrict__ out, uint64_t npoly, uint32_t n_ring, uint64_t seed, uint32_t stream,
+                        uint32_t kappa) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int8_t* mark = reinterpret_cast<int8_t*>(smem) + (size_t)wave * n_ring;
+  for (uint64_t poly = (uint64_t)blockIdx.x * 4 + wave; poly < npoly; poly += (uint64_t)gridDim.x * 4) {
+    for (uint32_t i = lane; i < n_ring; i += 64) mark[i] = 0;
+    wave_sync();
+    if (lane == 0) {
+      const uint32_t kap = kappa < n_ring ? kappa : n_ring;
+      Philox4 r{};
+      for (uint32_t t = 0; t < kap; ++t) {   // Floyd: a uniform kap-subset of [0, n_ring)
+        if ((t & 1) == 0) r = sampler_block(seed, stream, poly, t >> 1);
+        const uint32_t j = n_ring - kap + t;
+        const uint32_t w0 = r.v[(t & 1) * 2], w1 = r.v[(t & 1) * 2 + 1];
+        const uint32_t pick = uniform_below(w0, w1 & ~1u, j + 1);
+        const uint32_t pos = mark[pick] ? j : pick;
+        mark[pos] = (w1 & 1u) ? 1 : -1;   // random_bool(0.5): +1 / -1
+      }
+    }
+    wave_sync();
+    int64_t* dst = out + poly * n_ring;
+    for (uint32_t i = lane; i < n_ring; i += 64) dst[i] = (int64_t)mark[i];
+    wave_sync();
+  }
+}
+
+// =============================================================================================
 // Launchers
 // =============================================================================================
 static inline unsigned grid_for(uint64_t tasks, int num_cus, int waves_per_block = 4, int blocks_per_cu = 8) {
@@ -1460,6 +1547,33 @@ int launch_fill_u8(const LaunchCfg& cfg, uint8_t* p, uint8_t value, uint64_t n) 
   uint64_t blocks = (n + 255) / 256;
   if (blocks > 1024) blocks = 1024;
   hipLaunchKernelGGL(fill_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)cfg.stream, p, value, n);
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_sample_uniform(const LaunchCfg& cfg, int64_t* out, uint64_t npoly, uint32_t n_ring, uint64_t seed,
+                          uint32_t stream, uint32_t bound) {
+  if (npoly == 0) return 0;
+  const uint64_t ncoef = npoly * n_ring;
+  hipLaunchKernelGGL(sample_uniform_kernel, dim3(grid_for((ncoef + 3) / 4, cfg.num_cus, 256, 16)), dim3(256), 0,
+                     (hipStream_t)cfg.stream, out, ncoef, n_ring, seed, stream, bound);
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+int launch_sample_gauss(const LaunchCfg& cfg, int64_t* out, uint64_t npoly, uint32_t n_ring, uint64_t seed,
+                        uint32_t stream, double sigma) {
+  if (npoly == 0) return 0;
+  const uint64_t ncoef = npoly * n_ring;
+  hipLaunchKernelGGL(sample_gauss_kernel, dim3(grid_for((ncoef + 3) / 4, cfg.num_cus, 256, 16)), dim3(256), 0,
+                     (hipStream_t)cfg.stream, out, ncoef, n_ring, seed, stream, sigma);
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+int launch_sample_challenge(const LaunchCfg& cfg, int64_t* out, uint64_t npoly, uint32_t n_ring, uint64_t seed,
+                            uint32_t stream, uint32_t kappa) {
+  if (npoly == 0) return 0;
+  hipLaunchKernelGGL(sample_challenge_kernel, dim3(grid_for(npoly, cfg.num_cus, 4, 16)), dim3(256), 4 * n_ring,
+                     (hipStream_t)cfg.stream, out, npoly, n_ring, seed, stream, kappa);
   RZK_LAUNCH_CHECK();
   return 0;
 }

@@ -8,6 +8,7 @@
 
 #include "../../ring_zk_amd/csrc/rzk_core.h"
 #include "../../ring_zk_amd/csrc/rzk_tables.h"
+#include "../../ring_zk_amd/csrc/rzk_rng.h"
 
 using namespace rzk;
 
@@ -186,6 +187,11 @@ int emul_polymul(int logn, int np, uint64_t q, const int64_t* a, const int64_t* 
   }
   return -1;
 }
+void emul_philox(const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
+  const Philox4 r = philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+  for (int i = 0; i < 4; ++i) out[i] = r.v[i];
+}
+uint32_t emul_uniform_below(uint32_t hi, uint32_t lo, uint32_t range) { return uniform_below(hi, lo, range); }
 uint32_t emul_prime(int pi) { return kPrimes[pi]; }
 uint32_t emul_psi(int pi, uint32_t N) { return host::psi_for(pi, N); }
 double emul_capacity(int np) { return host::crt_capacity(np); }

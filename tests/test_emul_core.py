@@ -24,6 +24,7 @@ HALF = (Q - 1) // 2
 def emul():
     so = os.path.join(EMUL_DIR, "libemul.so")
     srcs = [os.path.join(EMUL_DIR, "emul.cpp"),
+            os.path.join(HERE, "..", "ring_zk_amd", "csrc", "rzk_rng.h"),
             os.path.join(HERE, "..", "ring_zk_amd", "csrc", "rzk_core.h"),
             os.path.join(HERE, "..", "ring_zk_amd", "csrc", "rzk_tables.h")]
     if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
@@ -143,3 +144,30 @@ def test_emulated_shift_product(emul, logn, pair):
     assert np.array_equal(run(2, dd, c1), O.poly_mul(dd, c1))
     small = rng.integers(-1000, 1001, N, dtype=np.int64)
     assert np.array_equal(run(1, small, c1), O.poly_mul(small, c1))
+
+
+def test_philox_known_answers(emul):
+    """Philox4x32-10 vectors of the Random123 distribution (kat_vectors): the generator behind the samplers."""
+    kats = [
+        ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+        ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+        ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+         (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+    ]
+    for ctr, key, want in kats:
+        c = (C.c_uint32 * 4)(*ctr)
+        k = (C.c_uint32 * 2)(*key)
+        out = (C.c_uint32 * 4)()
+        emul.emul_philox(c, k, out)
+        assert tuple(out) == want
+    emul.emul_uniform_below.restype = C.c_uint32
+    emul.emul_uniform_below.argtypes = [C.c_uint32] * 3
+    assert emul.emul_uniform_below(0, 0, 3) == 0
+    assert emul.emul_uniform_below(0xffffffff, 0xffffffff, 3) == 2
+    assert emul.emul_uniform_below(0x80000000, 0, 3) == 1
+    assert emul.emul_uniform_below(0xffffffff, 0xffffffff, 0xffffffff) == 0xfffffffe
+    rng = np.random.default_rng(9)
+    for _ in range(200):
+        hi, lo, rg = (int(v) for v in rng.integers(0, 2 ** 32, 3))
+        rg = max(rg, 1)
+        assert emul.emul_uniform_below(hi, lo, rg) == (((hi << 32) | lo) * rg) >> 64

@@ -10,7 +10,7 @@ from ring_zk_amd import Context, synth
 
 N, n, k, l, B = 1024, 1, 3, 1, 4096
 dev = torch.device("cuda", 0)
-steps, warm = 30, 5
+steps, warm = 300, 150
 
 
 def run(S):

@@ -75,6 +75,10 @@ uint64_t rzk_verify_bound(const rzk_ctx* ctx);
  * entries equal to 0 or 1 are recognised and skipped / turned into plain additions. */
 int rzk_key_load(rzk_ctx* ctx, const int64_t* a_host);
 int rzk_key_load_dev(rzk_ctx* ctx, const int64_t* a_dev);
+/* CommitmentKey::new (src/commit.rs:33-60) with the device-side sampler: a1 = [I_n | U], a2 = [0 | I_l | U],
+ * U uniform over [-(q-1)/2, (q-1)/2] (src/params.rs:126), drawn from (seed); the key is loaded and, when
+ * a_host_out != NULL, also returned ([n+l][k][N], the public key material).  Statistical parity (see samplers). */
+int rzk_key_generate(rzk_ctx* ctx, uint64_t seed, int64_t* a_host_out);
 
 /* ---- ring / Mat primitives (the Mat seam) ------------------------------------------------------------ */
 /* Polynomial::mul (src/prove/linear.rs:94; src/mat.rs:110,176): out[i] = a[i] * b[i], count polys */

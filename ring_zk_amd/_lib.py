@@ -33,6 +33,7 @@ SIGNATURES = {
     "rzk_verify_bound": (C.c_uint64, [_CTX]),
     "rzk_key_load": (C.c_int, [_CTX, _I64]),
     "rzk_key_load_dev": (C.c_int, [_CTX, _I64]),
+    "rzk_key_generate": (C.c_int, [_CTX, C.c_uint64, _I64]),
     "rzk_polymul_batch": (C.c_int, [_CTX, _I64, _I64, _I64, _SZ]),
     "rzk_matvec_batch": (C.c_int, [_CTX, C.c_int, _I64, _I64, _I64, _SZ]),
     "rzk_cmul_batch": (C.c_int, [_CTX, _I64, C.c_uint32, _I64, _I64, _SZ]),

@@ -126,6 +126,12 @@ class Context:
         return int(np.prod(a.shape[:-len(tail)], dtype=np.int64)) if a.ndim > len(tail) else 1
 
     # ---- key ---------------------------------------------------------------------------------------
+    def generate_key(self, seed: int) -> np.ndarray:
+        """CommitmentKey::new (commit.rs:33-60) from the device-side sampler; loads the key and returns it."""
+        a = np.empty((self.n + self.l, self.k, self.N), dtype=np.int64)
+        self._check(self._L.rzk_key_generate(self._h, seed, C.c_void_p(a.ctypes.data)))
+        return a
+
     def load_key(self, A):
         """CommitmentKey as the dense matrix [a1;a2] ((n+l) x k polynomials; src/commit.rs:109-114)."""
         self._shape(A, self.n + self.l, self.k, self.N)

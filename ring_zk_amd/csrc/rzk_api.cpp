@@ -943,6 +943,43 @@ int rzk_key_load(rzk_ctx* c, const int64_t* a_host) {
   return key_load_impl(c, a_host);
 }
 
+// CommitmentKey::new (commit.rs:33-60) with the device-side sampler: a1 = [I_n | U], a2 = [0_{l x n} | I_l | U],
+// U uniform over the centred range (params.rs:126).  The full key goes back to the caller (the reference's
+// CommitmentKey is public data) and is loaded like any other key.
+int rzk_key_generate(rzk_ctx* c, uint64_t seed, int64_t* a_host_out) {
+  if (!c) return RZK_E_ARG;
+  HIPCHK(c, hipSetDevice(c->device));
+  const uint32_t N = c->N, n = c->n, k = c->k, l = c->l;
+  const size_t n_rand = (size_t)n * (k - n) + (size_t)l * (k - n - l);
+  std::vector<int64_t> rnd(n_rand * N);
+  if (n_rand) {
+    int rc = arena_reserve(c, c->stage, n_rand * N * sizeof(int64_t));
+    if (rc != RZK_OK) return rc;
+    rc = check_launch(c, launch_sample_uniform(cfg_of(c), (int64_t*)c->stage.p, n_rand, N, seed, 0x6b6579u /* "key" */,
+                                               (uint32_t)((c->q - 1) / 2)),
+                      "key sampler");
+    if (rc != RZK_OK) return rc;
+    HIPCHK(c, hipMemcpyAsync(rnd.data(), c->stage.p, rnd.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  std::vector<int64_t> a((size_t)(n + l) * k * N, 0);
+  size_t next = 0;
+  auto put_random = [&](size_t row, size_t col) {
+    std::memcpy(a.data() + (row * k + col) * N, rnd.data() + next * N, (size_t)N * sizeof(int64_t));
+    ++next;
+  };
+  for (uint32_t i = 0; i < n; ++i) {          // a1 = [I_n | a1']   (commit.rs:38-46)
+    a[((size_t)i * k + i) * N] = 1;
+    for (uint32_t j = n; j < k; ++j) put_random(i, j);
+  }
+  for (uint32_t i = 0; i < l; ++i) {          // a2 = [0 | I_l | a2']  (commit.rs:48-57)
+    a[((size_t)(n + i) * k + n + i) * N] = 1;
+    for (uint32_t j = n + l; j < k; ++j) put_random(n + i, j);
+  }
+  if (a_host_out) std::memcpy(a_host_out, a.data(), a.size() * sizeof(int64_t));
+  return key_load_impl(c, a.data());
+}
+
 int rzk_key_load_dev(rzk_ctx* c, const int64_t* a_dev) {
   if (!c || !a_dev) return RZK_E_ARG;
   HIPCHK(c, hipSetDevice(c->device));

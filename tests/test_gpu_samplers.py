@@ -120,3 +120,39 @@ def test_bad_arguments(ctx):
         ctx.sample_uniform(1, 0, HALF + 1, (4,))          # beyond the centred range
     with pytest.raises(RzkError):
         ctx.sample_gauss(1, 0, 0.0, (4,))
+
+
+@pytest.mark.parametrize("shape", [(1024, 1, 3, 1), (512, 2, 5, 2), (16, 1, 3, 1)])
+def test_generated_key_has_the_reference_structure(shape):
+    """CommitmentKey::new (commit.rs:33-60): a1 = [I_n | U], a2 = [0 | I_l | U]; a commitment made with the
+    generated key verifies against the oracle, which takes the key as plain data."""
+    from ring_zk_amd import Context
+
+    N, n, k, l = shape
+    c = Context(N, n, k, l)
+    A = c.generate_key(77)
+    assert A.shape == (n + l, k, N)
+    one = np.zeros(N, dtype=np.int64)
+    one[0] = 1
+    for i in range(n):
+        for j in range(n):
+            assert np.array_equal(A[i, j], one if i == j else 0 * one)
+    for i in range(l):
+        for j in range(n):
+            assert not A[n + i, j].any()
+        for j in range(l):
+            assert np.array_equal(A[n + i, n + j], one if i == j else 0 * one)
+    rnd = np.concatenate([A[:n, n:].ravel(), A[n:, n + l:].ravel()]).astype(np.float64)
+    assert np.abs(rnd).max() <= HALF and rnd.size == (n * (k - n) + l * (k - n - l)) * N
+    if rnd.size >= 4096:
+        assert abs(rnd.std() / (Q / np.sqrt(12)) - 1) < 0.05
+    assert not np.array_equal(c.generate_key(78), A)
+    assert np.array_equal(c.generate_key(77), A)          # deterministic in the seed; key 77 is loaded again
+    rng = np.random.default_rng(2)
+    P = O.Params(N, n, k, l)
+    x = rng.integers(-HALF, HALF + 1, (1, l, N))
+    r = rng.integers(-1, 2, (1, k, N))
+    cm, ok = c.commit(x, r)
+    c_ref, ok_ref = O.commit(P, A, x[0], r[0])
+    assert np.array_equal(cm[0], c_ref) and bool(ok[0]) == ok_ref
+    assert O.commitment_verify(P, A, cm[0], x[0], r[0])

@@ -54,6 +54,7 @@ struct DevProg {
   uint32_t ngroups = 0;   // > 0: row groups (row_group_kernel)
   bool shift = false;     // every product has the sparse challenge as multiplier: shift_row_kernel
   bool has_shift = false; // some rows end with challenge products evaluated by rotations inside row_kernel
+  bool two_bit = false;   // two-bit verdict flags (CHECK2 marks)
 };
 
 struct Arena {   // grow-only device buffer
@@ -153,6 +154,7 @@ int arena_reserve(rzk_ctx* c, Arena& a, size_t bytes) {
 struct PB {
   Program p{};
   bool overflow = false;
+  bool two_bit = false;      // the program carries CHECK2 marks: two-bit verdict flags (row_kernel only)
   uint32_t sparse_ops = 0;   // bit i: operand i is a challenge (kappa-sparse, +-1): products with it may use shift-add
   int cur = -1;
   void begin_row(uint8_t out_op, uint32_t out_off, uint8_t mode) {
@@ -222,22 +224,24 @@ struct PB {
 // Fused norm predicate: mark, for each polynomial (vop, 0..count-1), the first load in program order
 // (b operand of a product term, or one of the first four additions of a row).  Returns false when some
 // polynomial is never loaded by the program — the caller then keeps the separate norm kernel.
-bool mark_checks(PB& pb, uint8_t vop, uint32_t count) {
+bool mark_checks(PB& pb, uint8_t vop, uint32_t count, bool second = false) {
+  const uint8_t tmark = second ? TERM_CHECK2 : TERM_CHECK, amark = second ? ADD_CHECK2 : ADD_CHECK;
+  if (second) pb.two_bit = true;
   for (uint32_t j = 0; j < count; ++j) {
     bool done = false;
     for (uint32_t r = 0; r < pb.p.nrows && !done; ++r) {
       const Row& row = pb.p.rows[r];
       for (uint32_t t = 0; t < row.nterms && !done; ++t) {
         Term& tm = pb.p.terms[row.term0 + t];
-        if (tm.b_op == vop && tm.b_off == j && !(tm.kind & TERM_CHECK)) {
-          tm.kind |= TERM_CHECK;
+        if (tm.b_op == vop && tm.b_off == j && !(tm.kind & (TERM_CHECK | TERM_CHECK2))) {
+          tm.kind |= tmark;
           done = true;
         }
       }
       for (uint32_t a = 0; a < row.nadds && a < 4 && !done; ++a) {
         AddTerm& ad = pb.p.adds[row.add0 + a];
-        if ((ad.op & ADD_OP_MASK) == vop && ad.off == j && !(ad.op & ADD_CHECK)) {
-          ad.op |= ADD_CHECK;
+        if ((ad.op & ADD_OP_MASK) == vop && ad.off == j && !(ad.op & (ADD_CHECK | ADD_CHECK2))) {
+          ad.op |= amark;
           done = true;
         }
       }
@@ -378,6 +382,9 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
         pb.begin_row(10, i, MODE_STORE);
         key_row(c, pb, +1, n + i, 4, 0);
       }
+      if (var & 1) {   // fused check_commit_constraint: r -> bit 0, rp -> bit 1 of ok (the two commits of linear.rs:96-97)
+        if (!mark_checks(pb, 2, k) || !mark_checks(pb, 3, k, true)) return RZK_E_UNSUPPORTED;
+      }
       break;
     case PG_LIN_U:   // ops: 0 = a2y[l], 1 = g, 2 = yp[k], 3 = u[l] : u = a2y(.)g - a2.yp (linear.rs:124-129)
       for (uint32_t i = 0; i < l; ++i) {
@@ -486,7 +493,8 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
     dp.shift = all;
   }
   for (uint32_t r = 0; r < pb.p.nrows; ++r) dp.has_shift = dp.has_shift || pb.p.rows[r].nshift > 0;
-  if (!c->small && c->use_groups && !dp.shift) {
+  dp.two_bit = pb.two_bit;
+  if (!c->small && c->use_groups && !dp.shift && !dp.two_bit) {
     bool key_only = pb.p.nterms > 0;
     for (uint32_t t = 0; t < pb.p.nterms; ++t) key_only = key_only && (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_KEY;
     if (key_only) {
@@ -524,7 +532,8 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
   for (uint32_t t = 0; t < pb.p.nterms; ++t) dp.has_vec = dp.has_vec || (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_VEC;
   // distinct operands of the product terms ("slots"); when rows share them often enough, transform each
   // once per proof (shared-operand path) instead of once per row
-  if (!c->small && c->slot_share_min > 0 && pb.p.nterms > 0 && dp.ngroups == 0 && !dp.shift && !dp.has_shift) {
+  if (!c->small && c->slot_share_min > 0 && pb.p.nterms > 0 && dp.ngroups == 0 && !dp.shift && !dp.has_shift &&
+      !dp.two_bit) {
     std::vector<SlotTable> stv(1);
     SlotTable& st = stv[0];
     std::memset(&st, 0, sizeof(st));
@@ -593,6 +602,7 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
     ops.outer[i] = specs[i].outer ? 1 : 0;
   }
   ops.group = group ? group : 1;
+  ops.pad = dp.two_bit ? 1 : 0;
   ops.norm_limit = norm_limit;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->prof) {
@@ -685,8 +695,11 @@ int run_program_checked(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSp
   DevProg dp;
   int rc = get_program(c, id, var | 1, dp);
   if (rc != RZK_OK) return rc;
+  // two-bit verdicts are cleared with word atomics: the flag array must be made of whole aligned words
+  if (dp.two_bit && ((reinterpret_cast<uintptr_t>(flags) & 3u) || (nflags & 3u))) return RZK_E_UNSUPPORTED;
+  const uint8_t all_ok = dp.two_bit ? 3 : 1;
   if (preset) {
-    rc = check_launch(c, launch_fill_u8(cfg_of(c), flags, 1, nflags), "flag preset");
+    rc = check_launch(c, launch_fill_u8(cfg_of(c), flags, all_ok, nflags), "flag preset");
     if (rc != RZK_OK) return rc;
   }
   return run_program(c, id, var | 1, specs, flags, group, batch, lim);
@@ -1153,14 +1166,22 @@ int rzk_linear_commit_batch_dev(rzk_ctx* c, const int64_t* g, const int64_t* x, 
   // linear.rs:91-95: gx = x_i * g
   rc = run_program(c, PG_CMUL, l, {{x, l, 0}, {g, 1, 0}, {gx, l, 0}}, nullptr, 1, B);
   if (rc != RZK_OK) return rc;
-  rc = run_program(c, PG_LIN_COMMIT2, 0,
-                   {{x, l, 0}, {gx, l, 0}, {r, k, 0}, {rp, k, 0}, {y, k, 0}, {yp, k, 0}, {cm, n + l, 0},
-                    {cpm, n + l, 0}, {t, n, 0}, {tp, n, 0}, {a2y, l, 0}},
-                   nullptr, 1, B);
-  if (rc != RZK_OK) return rc;
+  const std::vector<OpSpec> c2 = {{x, l, 0}, {gx, l, 0}, {r, k, 0}, {rp, k, 0}, {y, k, 0}, {yp, k, 0}, {cm, n + l, 0},
+                                  {cpm, n + l, 0}, {t, n, 0}, {tp, n, 0}, {a2y, l, 0}};
+  // the norm predicates on r (bit 0 of ok) and rp (bit 1) ride on the commit rows when the kernel path allows
+  bool fused = false;
+  if (ok) {
+    rc = run_program_checked(c, PG_LIN_COMMIT2, 0, c2, ok, 1, B, B, c->commit_bound);
+    if (rc != RZK_OK && rc != RZK_E_UNSUPPORTED) return rc;
+    fused = rc == RZK_OK;
+  }
+  if (!fused) {
+    rc = run_program(c, PG_LIN_COMMIT2, 0, c2, nullptr, 1, B);
+    if (rc != RZK_OK) return rc;
+  }
   rc = run_program(c, PG_LIN_U, 0, {{a2y, l, 0}, {g, 1, 0}, {yp, k, 0}, {u, l, 0}}, nullptr, 1, B);
   if (rc != RZK_OK) return rc;
-  if (ok) {
+  if (ok && !fused) {
     rc = run_norm(c, r, k, c->commit_bound, ok, B, 0, 0);
     if (rc != RZK_OK) return rc;
     rc = run_norm(c, rp, k, c->commit_bound, ok, B, 2, 1);
@@ -1217,18 +1238,28 @@ int rzk_sum_commit_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* gs, const in
   rc = run_program(c, PG_SUM_XP, V, {{xs, V * l, 0}, {gs, V, 0}, {xp, l, 0}}, nullptr, 1, B);
   if (rc != RZK_OK) return rc;
   // sum.rs:116 and 151: cp = commit(xp; rp), tp = a1.yp
-  rc = run_program(c, PG_OPEN_COMMIT, 0, {{xp, l, 0}, {rp, k, 0}, {yp, k, 0}, {cpm, n + l, 0}, {tp, n, 0}}, nullptr, 1, B);
-  if (rc != RZK_OK) return rc;
-  // sum.rs:117-120 and 145-148: c_i = commit(x_i; r_i), t_i = a1.y_i — the V summands are extra batch entries
-  rc = run_program(c, PG_OPEN_COMMIT, 0, {{xs, l, 0}, {rs, k, 0}, {ys, k, 0}, {cs, n + l, 0}, {ts, n, 0}}, nullptr, 1,
-                   B * V);
-  if (rc != RZK_OK) return rc;
+  const std::vector<OpSpec> cp_specs = {{xp, l, 0}, {rp, k, 0}, {yp, k, 0}, {cpm, n + l, 0}, {tp, n, 0}};
+  const std::vector<OpSpec> cs_specs = {{xs, l, 0}, {rs, k, 0}, {ys, k, 0}, {cs, n + l, 0}, {ts, n, 0}};
+  // ok[b] = constraint(rp_b) && all_i constraint(r_{b,i}): fused into the commit rows when possible
+  const bool fused = ok && can_fuse(c, PG_OPEN_COMMIT, 0, c->commit_bound);
+  if (fused) {
+    rc = run_program_checked(c, PG_OPEN_COMMIT, 0, cp_specs, ok, 1, B, B, c->commit_bound, true);
+    if (rc != RZK_OK) return rc;
+    // sum.rs:117-120 and 145-148: c_i = commit(x_i; r_i), t_i = a1.y_i — the V summands are extra batch entries
+    rc = run_program_checked(c, PG_OPEN_COMMIT, 0, cs_specs, ok, V, B * V, B, c->commit_bound, false);
+    if (rc != RZK_OK) return rc;
+  } else {
+    rc = run_program(c, PG_OPEN_COMMIT, 0, cp_specs, nullptr, 1, B);
+    if (rc != RZK_OK) return rc;
+    rc = run_program(c, PG_OPEN_COMMIT, 0, cs_specs, nullptr, 1, B * V);
+    if (rc != RZK_OK) return rc;
+  }
   // sum.rs:154-160: u = sum_i (a2.y_i)(.)g_i - a2.yp
   rc = run_program(c, PG_MATVEC, RZK_KEY_A2 * 2, {{ys, k, 0}, {nullptr, l, 0}, {w, l, 0}}, nullptr, 1, B * V);
   if (rc != RZK_OK) return rc;
   rc = run_program(c, PG_SUM_U, V, {{w, V * l, 0}, {gs, V, 0}, {yp, k, 0}, {u, l, 0}}, nullptr, 1, B);
   if (rc != RZK_OK) return rc;
-  if (ok) {
+  if (ok && !fused) {
     rc = run_norm(c, rp, k, c->commit_bound, ok, B, 0, 0);
     if (rc != RZK_OK) return rc;
     rc = run_norm(c, rs, V * k, c->commit_bound, ok, B, 1, 0);

@@ -36,15 +36,19 @@ constexpr int kMaxAdds = 128;
 // TERM_SHIFT: (a_op,a_off) (*) (b_op,b_off) with a sparse `a` (the challenge d), evaluated as signed negacyclic
 // rotations (ShiftGeo, rzk_core.h) instead of transforms.  A row keeps its shift terms behind its transform
 // terms: terms[term0 .. term0+nterms) are KEY / VEC, terms[term0+nterms .. +nshift) are SHIFT.
-enum : uint8_t { TERM_KEY = 0, TERM_VEC = 1, TERM_SHIFT = 2, TERM_KIND_MASK = 0x7f };
+enum : uint8_t { TERM_KEY = 0, TERM_VEC = 1, TERM_SHIFT = 2, TERM_KIND_MASK = 0x3f };
 enum : uint8_t { MODE_STORE = 0, MODE_ZERO = 1 };
 // Fused norm predicate (Params::check_*_constraint, src/params.rs:102-118): a term (its b operand) or an
 // addition marked with CHECK also tests sum c^2 < Operands::norm_limit for the polynomial it loads and
 // clears flags[proof] on failure.  The host marks, for each polynomial of the checked vector, the first
 // load in program order, so every polynomial is tested exactly once and no separate norm pass is needed.
+// CHECK2 marks a second checked vector whose failure clears only bit 1 of the flag byte (two-bit verdicts:
+// Linear commit reports constraint(r) in bit 0 and constraint(r') in bit 1); it is honoured by row_kernel only.
 constexpr uint8_t TERM_CHECK = 0x80;   // in Term::kind
+constexpr uint8_t TERM_CHECK2 = 0x40;
 constexpr uint8_t ADD_CHECK = 0x80;    // in AddTerm::op
-constexpr uint8_t ADD_OP_MASK = 0x7f;
+constexpr uint8_t ADD_CHECK2 = 0x40;
+constexpr uint8_t ADD_OP_MASK = 0x3f;
 
 struct Term {
   uint8_t kind;     // TERM_KEY: KEY[a_off] (*) operand(b_op, b_off);  TERM_VEC: (a_op,a_off) (*) (b_op,b_off)
@@ -96,7 +100,7 @@ struct Operands {
   uint32_t stride[kMaxOperands];
   uint32_t outer[kMaxOperands];
   uint32_t group;
-  uint32_t pad;
+  uint32_t pad;          // != 0: two-bit verdict flags (TERM_CHECK clears bit 0, TERM_CHECK2 bit 1; row_kernel only)
   uint64_t norm_limit;   // (bound+1)^2 of the fused norm predicate; must be <= 2^48 (0 = unused)
 };
 

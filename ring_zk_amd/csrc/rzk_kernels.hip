@@ -75,6 +75,21 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   return v;
 }
 
+// Verdict of a failed norm predicate.  One-bit flags (two_bit == false): the byte is cleared with a plain store
+// (idempotent, any number of rows may do it).  Two-bit flags: bit 0 or bit 1 is cleared with an agent-scope
+// atomic AND on the aligned word that holds the byte, because rows of one proof on different XCDs may clear
+// different bits (the host only enables this when the flag array is word aligned and a multiple of 4 long).
+__device__ __forceinline__ void fail_check(uint8_t* flag, bool two_bit, bool second) {
+  if (!two_bit) {
+    *flag = 0;
+    return;
+  }
+  const uintptr_t a = reinterpret_cast<uintptr_t>(flag);
+  const uint32_t bit = (second ? 2u : 1u) << (8u * (uint32_t)(a & 3u));
+  __hip_atomic_fetch_and(reinterpret_cast<uint32_t*>(a & ~(uintptr_t)3), ~bit, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ const int64_t* operand_ptr(const Operands& ops, uint32_t op, uint32_t off,
                                                        uint32_t b, uint32_t bo, int n_coef) {
   const uint32_t idx = ops.outer[op] ? bo : b;
@@ -290,9 +305,9 @@ __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const 
   uint32_t x[E];
   double l1b = 0, infb = 0;
   uint64_t sumsq = 0;
-  const bool chk = first && (tm.kind & TERM_CHECK);
+  const bool chk = first && (tm.kind & (TERM_CHECK | TERM_CHECK2));
   load_lift<LOGN>(x, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), ln, pc, first, l1b, infb, chk, sumsq);
-  if (chk && sumsq >= ops.norm_limit && lane == 0) flags[bo] = 0;
+  if (chk && sumsq >= ops.norm_limit && lane == 0) fail_check(flags + bo, ops.pad != 0, (tm.kind & TERM_CHECK2) != 0);
   wave_fwd<LOGN>(x, ln, lds, twf, pc);
   if (HAS_VEC && (tm.kind & TERM_KIND_MASK) == TERM_VEC) {
     // product of two per-proof polynomials: fold N^-1 and the Montgomery factor into one of them
@@ -411,7 +426,7 @@ __device__ __forceinline__ void row_epilogue(const Program* __restrict__ prog, c
       int32_t av[CH];
 #pragma unroll
       for (int i = 0; i < CH; ++i) av[i] = (int32_t)src[G::j_p1(lane, e0 + i)];
-      if (ad.op & ADD_CHECK) {
+      if (ad.op & (ADD_CHECK | ADD_CHECK2)) {
         uint64_t sq = 0;
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
@@ -445,12 +460,13 @@ __device__ __forceinline__ void row_epilogue(const Program* __restrict__ prog, c
     // checked additions: the host marks them only among the first four additions of a row
 #pragma unroll 1
     for (uint32_t a = 0; a < row.nadds && a < 4; ++a) {
-      if (prog->adds[row.add0 + a].op & ADD_CHECK) {
+      const uint8_t aop = prog->adds[row.add0 + a].op;
+      if (aop & (ADD_CHECK | ADD_CHECK2)) {
         uint64_t tot = 0;
 #pragma unroll
         for (int sl = 0; sl < 4; ++sl) tot = (sl == (int)a) ? add_sq[sl] : tot;
         tot = wave_sum_u64(tot);
-        if (tot >= ops.norm_limit && lane == 0) flags[bo] = 0;
+        if (tot >= ops.norm_limit && lane == 0) fail_check(flags + bo, ops.pad != 0, (aop & ADD_CHECK2) != 0);
       }
     }
   }

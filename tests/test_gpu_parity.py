@@ -514,3 +514,38 @@ def test_commit_and_commitment_verify(torch_mod, shape):
     assert gd.cpu().numpy().tolist() == ctx.commitment_verify(c, x, rf, f).tolist()
     cd, okd = ctx.commit(dev(torch_mod, x), dev(torch_mod, r))
     assert np.array_equal(cd.cpu().numpy(), c) and np.array_equal(okd.cpu().numpy(), ok)
+
+
+@pytest.mark.parametrize("N", [512, 1024])
+def test_linear_commit_two_bit_verdicts(torch_mod, N):
+    """ok[b] of the Linear commit: bit 0 = constraint(r), bit 1 = constraint(r') (the two ck.commit calls of
+    linear.rs:96-97).  With a word-aligned flag array of a multiple of 4 proofs both predicates ride on the commit
+    rows (atomic clears of single bits); all four bit patterns must come out, next to each other in one word."""
+    n, k, l = 1, 3, 1
+    ctx = ctx_for(N, n, k, l)
+    P = _P(ctx)
+    rng = np.random.default_rng(77 + N)
+    A = synth.key(rng, N, n, k, l)
+    ctx.load_key(A)
+    B = 8
+    g = synth.uniform(rng, (B, N))
+    x = synth.uniform(rng, (B, l, N))
+    r, rp = synth.small(rng, (B, k, N)), synth.small(rng, (B, k, N))
+    y, yp = synth.gauss(rng, (B, k, N), P.sigma), synth.gauss(rng, (B, k, N), P.sigma)
+    big = synth.uniform(rng, (k, N))
+    r[1], rp[2], r[3], rp[3] = big, big, big, big            # patterns 2, 1, 0 in one flag word
+    r[6, k - 1] = big[0]                                     # only the LAST polynomial of r violates the bound
+    rp[7, 0] = big[1]                                        # only the FIRST polynomial of r'
+    want_ok = [3, 2, 1, 0, 3, 3, 2, 1]
+    for conv in (lambda a: a, lambda a: dev(torch_mod, a)):
+        out = ctx.linear_commit(*(conv(a) for a in (g, x, r, rp, y, yp)))
+        c, cp, t, tp, u, ok = (o if isinstance(o, np.ndarray) else o.cpu().numpy() for o in out)
+        assert ok.tolist() == want_ok
+        for b in range(B):
+            ref = O.linear_commit(P, A, g[b], x[b], r[b], rp[b], y[b], yp[b])
+            for got, want in zip((c, cp, t, tp, u), ref[:5]):
+                assert np.array_equal(got[b], want)
+            assert int(ok[b]) == ref[5]
+    # a batch that is not a multiple of 4 takes the separate norm kernels: same verdicts
+    out = ctx.linear_commit(g[:7], x[:7], r[:7], rp[:7], y[:7], yp[:7])
+    assert out[5].tolist() == want_ok[:7]

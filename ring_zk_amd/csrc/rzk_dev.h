@@ -127,7 +127,10 @@ size_t group_scratch_words(int logn, int num_cus);
 int launch_shift_rows(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows, const Operands& ops,
                       const DevTables* d_T, uint8_t* d_flags, uint64_t batch);
 // rows per group; 1 = no grouping (at N = 2048 the accumulators cost too many registers: measured slower)
-inline int group_max_for(int logn) { return logn >= 11 ? 1 : kGroupMax; }
+#ifndef RZK_GROUP_GM
+#define RZK_GROUP_GM 4   // accumulators (= rows per group) of row_group_kernel at N <= 1024; at most kGroupMax
+#endif
+inline int group_max_for(int logn) { return logn >= 11 ? 1 : RZK_GROUP_GM; }
 // words of per-wave global scratch the row kernel needs: (max blocks) * 4 waves * 2N (Garner word B, shift sums)
 size_t row_scratch_words(int logn, int num_cus);
 int launch_key_transform(int logn, const LaunchCfg& cfg, const int64_t* d_key, uint32_t entries,

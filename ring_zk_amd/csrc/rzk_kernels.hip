@@ -650,6 +650,9 @@ shift_row_kernel(const Program* __restrict__ prog, const Operands ops, const Dev
 // list: each operand is loaded, measured and transformed once per prime and multiplied into one
 // accumulator per row.  For [a1;a2].r with (n,k,l) = (4,9,4) that is 23 transforms per prime instead of 56.
 // The Garner state of every row of the group lives in a per-wave global scratch line (L2 resident).
+#ifndef RZK_GROUP_OPAQUE
+#define RZK_GROUP_OPAQUE 1
+#endif
 #ifndef RZK_GROUP_MIN_WAVES
 #define RZK_GROUP_MIN_WAVES 1
 #endif
@@ -701,9 +704,11 @@ row_group_kernel(const Program* __restrict__ prog, const Operands ops, const uin
           double l1 = 0, linf = 0;
           uint64_t sumsq = 0;
           const bool chk = first && (tm0.kind & TERM_CHECK);
-          load_lift<LOGN>(x, operand_ptr(ops, tm0.b_op, tm0.b_off, b, bo, N), lane, pc, first, l1, linf, chk, sumsq);
+          int ln = lane;
+          if (RZK_GROUP_OPAQUE) asm volatile("" : "+v"(ln));   // no hoisting of lane-dependent addresses (register budget)
+          load_lift<LOGN>(x, operand_ptr(ops, tm0.b_op, tm0.b_off, b, bo, N), ln, pc, first, l1, linf, chk, sumsq);
           if (chk && sumsq >= ops.norm_limit && lane == 0) flags[bo] = 0;
-          wave_fwd<LOGN>(x, lane, lds, twf, pc);
+          wave_fwd<LOGN>(x, ln, lds, twf, pc);
 #pragma unroll
           for (int g = 0; g < GM; ++g) {
             if ((uint32_t)g < cnt) {
@@ -713,7 +718,7 @@ row_group_kernel(const Program* __restrict__ prog, const Operands ops, const uin
                   reinterpret_cast<const uint4*>(key_ntt + ((size_t)tg.a_off * kMaxPrimes + pi) * N);
 #pragma unroll
               for (int q4 = 0; q4 < E / 4; ++q4) {
-                const uint4 kv = kp[q4 * 64 + lane];
+                const uint4 kv = kp[q4 * 64 + ln];
                 const uint32_t ks[4] = {kv.x, kv.y, kv.z, kv.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -741,8 +746,8 @@ row_group_kernel(const Program* __restrict__ prog, const Operands ops, const uin
             for (int gg = 1; gg < GM; ++gg) v = g == (uint32_t)gg ? acc[gg][c] : v;
             w[c] = v;
           }
-          inverse_and_fold<LOGN>(pi, np, w, lane, lds, twf + kTableLen, pc, st + (size_t)(2 * g) * N,
-                                 st + (size_t)(2 * g + 1) * N, T);
+          inverse_and_fold<LOGN, RZK_GROUP_OPAQUE != 0>(pi, np, w, lane, lds, twf + kTableLen, pc, st + (size_t)(2 * g) * N,
+                                                        st + (size_t)(2 * g + 1) * N, T);
         }
       }
     }
@@ -1447,7 +1452,7 @@ static int launch_groups_t(const LaunchCfg& cfg, const Program* d_prog, const Op
                            const double* d_key_inf, const DevTables* T, const uint32_t* d_tw, uint32_t* d_scratch,
                            uint8_t* d_flags, uint32_t ntasks) {
   using G = Geo<LOGN>;
-  constexpr int GM = LOGN >= 11 ? 2 : kGroupMax;   // accumulators per wave (N = 2048 is never grouped by the host)
+  constexpr int GM = LOGN >= 11 ? 2 : RZK_GROUP_GM;   // accumulators per wave (N = 2048 is never grouped by the host)
   hipLaunchKernelGGL((row_group_kernel<LOGN, GM>), dim3(grid_for(ntasks, cfg.num_cus)), dim3(256),
                      4 * G::LDS_WORDS * sizeof(uint32_t), (hipStream_t)cfg.stream, d_prog, ops, d_key_ntt, d_key_inf, T,
                      d_tw, d_scratch, d_flags, ntasks);

@@ -41,6 +41,8 @@ enum ProgId : int {
   PG_SUM_V3,          // variant = V
   PG_COMMIT,          // c = [a1;a2].r + [0;x]                       (commit.rs:88-128)
   PG_COMMIT_VERIFY,   // variant bit 1: opening has a scalar f       (commit.rs:173-210)
+  PG_A1Z,             // w = a1.z (n rows), norm predicate on z fused (bit 0)   } the A1 relation in two steps for
+  PG_REL_ROT,         // w - c1(.)d - t == 0, all rotations                      } n >= 2: grouped rows + rotations
 };
 
 struct DevProg {
@@ -335,6 +337,24 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
         if (!mark_checks(pb, 1, k)) return RZK_E_UNSUPPORTED;
       }
       break;
+    case PG_A1Z:   // ops: 0 = z[k], 1 = w[n]
+      for (uint32_t i = 0; i < n; ++i) {
+        pb.begin_row(1, i, MODE_STORE);
+        key_row(c, pb, +1, i, 0, 0);
+      }
+      if (var & 1) {   // fused check_verify_constraint(z)
+        if (!mark_checks(pb, 0, k)) return RZK_E_UNSUPPORTED;
+      }
+      break;
+    case PG_REL_ROT:   // ops: 0 = w[n] (= a1.z), 1 = t[n], 2 = c[n+l], 3 = d ; flags &= (w == t + c1(.)d)
+      pb.sparse_ops = 1u << 3;
+      for (uint32_t i = 0; i < n; ++i) {
+        pb.begin_row(0, 0, MODE_ZERO);
+        pb.vec_term(-1, 3, 0, 2, i);
+        pb.add(+1, 0, i);
+        pb.add(-1, 1, i);
+      }
+      break;
     case PG_RESPONSE:   // ops: 0 = d, then per triple s: 1+3s = y[k], 2+3s = r[k], 3+3s = z[k]
       pb.sparse_ops = 1u << 0;
       for (uint32_t s = 0; s < var; ++s)
@@ -468,7 +488,7 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
 
 int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
   const bool needs_key = !(id == PG_POLYMUL || id == PG_CMUL || id == PG_RESPONSE || id == PG_SUM_XP ||
-                           id == PG_SUM_W2);
+                           id == PG_SUM_W2 || id == PG_REL_ROT);
   if (needs_key && !c->key_loaded) return fail(c, RZK_E_STATE, "commitment key not loaded");
   auto it = c->progs.find({id, var});
   if (it != c->progs.end()) {
@@ -1089,6 +1109,38 @@ int rzk_sample_challenge_dev(rzk_ctx* c, uint64_t seed, uint32_t stream, int64_t
   return check_launch(c, launch_sample_challenge(cfg_of(c), out, count, c->N, seed, stream, c->kappa), "sampler");
 }
 
+namespace {
+
+// accept &= check_verify_constraint(z) && (a1.z == t + c1 (.) d)      (open.rs:167-173, sum.rs:262-298)
+// specs: z[k], t[n], c[n+l], d.  group / batch / nflags as in run_program; preset: initialise accept.
+// n == 1: one launch, the d-product is a rotation term inside the relation row.  n >= 2 (and rotations +
+// row groups available): a1.z as ONE grouped launch (each z_j transformed once for the n rows, norm predicate
+// fused) into `w`, then the relation rows as pure rotations (shift_row_kernel) — 18 instead of 48 transform
+// units per (4,9,4) relation.
+int run_a1_relation(rzk_ctx* c, const std::vector<OpSpec>& specs, int64_t* w, uint8_t* accept, uint32_t group,
+                    uint64_t batch, uint64_t nflags, bool preset) {
+  const bool split = w && shift_ok(c) && c->use_groups && group_max_for((int)c->logn) > 1 && c->n >= 2;
+  int rc;
+  if (split) {
+    const std::vector<OpSpec> a1z = {specs[0], {w, c->n, 0}};
+    rc = run_program_checked(c, PG_A1Z, 0, a1z, accept, group, batch, nflags, c->verify_bound, preset);
+    if (rc == RZK_E_UNSUPPORTED) {
+      rc = run_norm(c, specs[0].base, group * c->k, c->verify_bound, accept, nflags, preset ? 0 : 1, 0);
+      if (rc != RZK_OK) return rc;
+      rc = run_program(c, PG_A1Z, 0, a1z, nullptr, group, batch);
+    }
+    if (rc != RZK_OK) return rc;
+    return run_program(c, PG_REL_ROT, 0, {{w, c->n, 0}, specs[1], specs[2], specs[3]}, accept, group, batch);
+  }
+  rc = run_program_checked(c, PG_A1_RELATION, 0, specs, accept, group, batch, nflags, c->verify_bound, preset);
+  if (rc != RZK_E_UNSUPPORTED) return rc;
+  rc = run_norm(c, specs[0].base, group * c->k, c->verify_bound, accept, nflags, preset ? 0 : 1, 0);
+  if (rc != RZK_OK) return rc;
+  return run_program(c, PG_A1_RELATION, 0, specs, accept, group, batch);
+}
+
+}  // namespace
+
 // =================================================================================================
 // Commitment scheme
 // =================================================================================================
@@ -1143,12 +1195,10 @@ int rzk_open_verify_batch_dev(rzk_ctx* c, const int64_t* z, const int64_t* t, co
   if (!c || !z || !t || !cm || !d || !accept) return RZK_E_ARG;
   if (c->n != c->l) return fail(c, RZK_E_ARG, "c1_c2 split needs n == l (reference panics in Mat::add)");
   const std::vector<OpSpec> specs = {{z, c->k, 0}, {t, c->n, 0}, {cm, c->n + c->l, 0}, {d, 1, 0}};
-  // open.rs:167-169: the norm predicate on z is fused into the rows that load z (one launch per verify)
-  int rc = run_program_checked(c, PG_A1_RELATION, 0, specs, accept, 1, B, B, c->verify_bound);
-  if (rc != RZK_E_UNSUPPORTED) return rc;
-  rc = run_norm(c, z, c->k, c->verify_bound, accept, B, 0, 0);
+  int rc = arena_reserve(c, c->ws, polys(c, B * c->n));
   if (rc != RZK_OK) return rc;
-  return run_program(c, PG_A1_RELATION, 0, specs, accept, 1, B);
+  // open.rs:167-173: the norm predicate on z rides on the rows that load z
+  return run_a1_relation(c, specs, (int64_t*)c->ws.p, accept, 1, B, B, true);
 }
 
 // =================================================================================================
@@ -1284,29 +1334,19 @@ int rzk_sum_verify_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* zs, const in
   if (!c || V == 0 || !zs || !zp || !cs || !cpm || !gs || !ts || !tp || !u || !d || !accept) return RZK_E_ARG;
   if (c->n != c->l) return fail(c, RZK_E_ARG, "c1_c2 split needs n == l (reference panics in Mat::add)");
   const uint32_t n = c->n, k = c->k, l = c->l;
-  int rc = arena_reserve(c, c->ws, polys(c, B * V * l + B * l));
+  int rc = arena_reserve(c, c->ws, polys(c, B * V * l + B * l + B * V * n));
   if (rc != RZK_OK) return rc;
   int64_t* w1 = (int64_t*)c->ws.p;
   int64_t* w2 = w1 + B * V * l * c->N;
+  int64_t* w0 = w2 + B * l * c->N;   // a1.z of the relation checks (n >= 2 only)
   const std::vector<OpSpec> rel_s = {{zs, k, 0}, {ts, n, 0}, {cs, n + l, 0}, {d, 1, 1}};
   const std::vector<OpSpec> rel_p = {{zp, k, 0}, {tp, n, 0}, {cpm, n + l, 0}, {d, 1, 0}};
-  if (can_fuse(c, PG_A1_RELATION, 0, c->verify_bound)) {
-    // sum.rs:262-271 norm predicates fused into sum.rs:278-291 (every summand; batch entries B*V, flag per
-    // proof) and sum.rs:294-298
-    rc = run_program_checked(c, PG_A1_RELATION, 0, rel_s, accept, V, B * V, B, c->verify_bound, true);
-    if (rc != RZK_OK) return rc;
-    rc = run_program_checked(c, PG_A1_RELATION, 0, rel_p, accept, 1, B, B, c->verify_bound, false);
-    if (rc != RZK_OK) return rc;
-  } else {
-    rc = run_norm(c, zs, V * k, c->verify_bound, accept, B, 0, 0);   // sum.rs:262-268
-    if (rc != RZK_OK) return rc;
-    rc = run_norm(c, zp, k, c->verify_bound, accept, B, 1, 0);       // sum.rs:269-271
-    if (rc != RZK_OK) return rc;
-    rc = run_program(c, PG_A1_RELATION, 0, rel_s, accept, V, B * V);   // sum.rs:278-291
-    if (rc != RZK_OK) return rc;
-    rc = run_program(c, PG_A1_RELATION, 0, rel_p, accept, 1, B);       // sum.rs:294-298
-    if (rc != RZK_OK) return rc;
-  }
+  // sum.rs:262-271 norm predicates ride on sum.rs:278-291 (every summand; batch entries B*V, flag per proof)
+  // and sum.rs:294-298
+  rc = run_a1_relation(c, rel_s, w0, accept, V, B * V, B, true);
+  if (rc != RZK_OK) return rc;
+  rc = run_a1_relation(c, rel_p, w0, accept, 1, B, B, false);
+  if (rc != RZK_OK) return rc;
   // sum.rs:301-319
   rc = run_program(c, PG_MATVEC, RZK_KEY_A2 * 2, {{zs, k, 0}, {nullptr, l, 0}, {w1, l, 0}}, nullptr, 1, B * V);
   if (rc != RZK_OK) return rc;

@@ -81,6 +81,7 @@ struct rzk_ctx {
   uint32_t* d_row_scratch = nullptr;   // per-wave Garner state of the row kernel (third prime only)
   uint32_t* d_group_scratch = nullptr; // per-wave Garner state of the row-group kernel (allocated on first use)
   bool use_groups = true;
+  int group_max = 1;                   // rows per group of row_group_kernel (group_max_for; RZK_GROUP_MAX overrides, tuning)
   bool use_shift = true;               // challenge products as signed rotations (shift_row_kernel) instead of transforms
   bool small = false;                  // N < 512: schoolbook kernels (rzk_kernels.hip, "small ring degrees")
   uint32_t r2q = 0;                    // 2^64 mod q
@@ -518,7 +519,7 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
     bool key_only = pb.p.nterms > 0;
     for (uint32_t t = 0; t < pb.p.nterms; ++t) key_only = key_only && (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_KEY;
     if (key_only) {
-      const uint32_t gmax = (uint32_t)group_max_for((int)c->logn);
+      const uint32_t gmax = (uint32_t)c->group_max;
       uint32_t ng = 0;
       for (uint32_t r = 0; r < pb.p.nrows;) {
         uint32_t cnt = 1;
@@ -825,6 +826,11 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
   c->stream = c->own_stream;
   if (const char* e = std::getenv("RZK_SLOT_SHARE_MIN")) c->slot_share_min = std::atof(e);   // tuning knobs
   if (const char* e = std::getenv("RZK_ROW_GROUPS")) c->use_groups = std::atoi(e) != 0;
+  c->group_max = group_max_for((int)c->logn);
+  if (const char* e = std::getenv("RZK_GROUP_MAX")) {
+    const int g = std::atoi(e);
+    if (g >= 1 && g <= (c->logn >= 11 ? 2 : RZK_GROUP_GM)) c->group_max = g;   // bounded by the compiled accumulators
+  }
   if (const char* e = std::getenv("RZK_SHIFT")) c->use_shift = std::atoi(e) != 0;
 
   // twiddle tables: 3 primes x {fwd, inv} x kTableLen
@@ -1119,7 +1125,7 @@ namespace {
 // units per (4,9,4) relation.
 int run_a1_relation(rzk_ctx* c, const std::vector<OpSpec>& specs, int64_t* w, uint8_t* accept, uint32_t group,
                     uint64_t batch, uint64_t nflags, bool preset) {
-  const bool split = w && shift_ok(c) && c->use_groups && group_max_for((int)c->logn) > 1 && c->n >= 2;
+  const bool split = w && shift_ok(c) && c->use_groups && c->group_max > 1 && c->n >= 2;
   int rc;
   if (split) {
     const std::vector<OpSpec> a1z = {specs[0], {w, c->n, 0}};

@@ -198,6 +198,9 @@ __device__ __forceinline__ void load_pairs(int32_t* v, const int64_t* __restrict
   }
 }
 
+#ifndef RZK_SHIFT_H
+#define RZK_SHIFT_H 8   // outputs of a lane accumulated per scan over the multiplier's non-zeros
+#endif
 // walk the non-zero coefficients of the multiplier (registers a[], lane-distributed in layout PAIR) and add
 // the rotations into IN outputs of every lane; `ext` already points at the first of them
 template <int LOGN, bool PAIR, int IN>
@@ -232,7 +235,7 @@ __device__ __forceinline__ void shift_product(uint32_t* res, bool fresh, bool mi
                                               const DevTables& T) {
   using S = ShiftGeo<LOGN, PAIR>;
   constexpr int E = S::E;
-  constexpr int H = 8;                 // outputs per scan; chunk c covers registers c*H .. c*H+H-1
+  constexpr int H = RZK_SHIFT_H < E ? RZK_SHIFT_H : E;   // outputs per scan; chunk c covers registers c*H .. c*H+H-1
   constexpr int NCH = E / H;
   const uint32_t q = T.crt.q;
   int npass = 1;

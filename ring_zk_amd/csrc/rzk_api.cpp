@@ -57,6 +57,8 @@ struct DevProg {
   bool shift = false;     // every product has the sparse challenge as multiplier: shift_row_kernel
   bool has_shift = false; // some rows end with challenge products evaluated by rotations inside row_kernel
   bool two_bit = false;   // two-bit verdict flags (CHECK2 marks)
+  BlockPlan* d_blocks = nullptr;   // row blocks (row_block_kernel): operands of a block staged once in LDS
+  uint32_t nblocks = 0;
 };
 
 struct Arena {   // grow-only device buffer
@@ -80,6 +82,8 @@ struct rzk_ctx {
   uint32_t* d_tw = nullptr;
   uint32_t* d_row_scratch = nullptr;   // per-wave Garner state of the row kernel (third prime only)
   uint32_t* d_group_scratch = nullptr; // per-wave Garner state of the row-group kernel (allocated on first use)
+  uint32_t* d_block_scratch = nullptr; // per-workgroup Garner state of the row-block kernel (allocated on first use)
+  uint32_t block_min_logn = 11;        // row blocks from this ring degree on (below it row groups do the sharing)
   bool use_groups = true;
   int group_max = 1;                   // rows per group of row_group_kernel (group_max_for; RZK_GROUP_MAX overrides, tuning)
   bool use_shift = true;               // challenge products as signed rotations (shift_row_kernel) instead of transforms
@@ -515,7 +519,71 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
   }
   for (uint32_t r = 0; r < pb.p.nrows; ++r) dp.has_shift = dp.has_shift || pb.p.rows[r].nshift > 0;
   dp.two_bit = pb.two_bit;
-  if (!c->small && c->use_groups && !dp.shift && !dp.two_bit) {
+  // Row blocks: key-only programs whose rows share operands; consecutive rows are packed into blocks of at
+  // most kBlockMaxRows rows and kBlockMaxSlots distinct operands.  Used when every operand is needed by at
+  // least two terms on average (otherwise nothing is shared and the plain row kernel is as good).
+  if (!c->small && c->logn >= 10 && c->logn >= c->block_min_logn && !dp.shift && !dp.has_shift && !dp.two_bit &&
+      pb.p.nterms > 0) {
+    bool key_only = true;
+    for (uint32_t t = 0; t < pb.p.nterms; ++t) key_only = key_only && (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_KEY;
+    std::vector<BlockPlan> planv(1);
+    BlockPlan& bp = planv[0];
+    std::memset(&bp, 0, sizeof(bp));
+    bool fits = key_only;
+    std::map<std::pair<uint32_t, uint32_t>, uint32_t> cur;   // (op, off) -> slot of the open block
+    auto open_block = [&](uint32_t row) {
+      bp.blk[bp.nblocks].row0 = (uint16_t)row;
+      bp.blk[bp.nblocks].nrows = 0;
+      bp.blk[bp.nblocks].slot0 = (uint16_t)bp.nslots_total;
+      bp.blk[bp.nblocks].nslots = 0;
+      cur.clear();
+    };
+    if (fits) open_block(0);
+    for (uint32_t r = 0; fits && r < pb.p.nrows; ++r) {
+      const Row& row = pb.p.rows[r];
+      std::map<std::pair<uint32_t, uint32_t>, uint32_t> add;   // operands this row brings that the block lacks
+      for (uint32_t t = 0; t < row.nterms; ++t) {
+        const Term& tm = pb.p.terms[row.term0 + t];
+        if (!cur.count({tm.b_op, tm.b_off})) add[{tm.b_op, tm.b_off}] = 0;
+      }
+      BlockDesc* bd = &bp.blk[bp.nblocks];
+      if (bd->nrows == kBlockMaxRows || bd->nslots + add.size() > (size_t)kBlockMaxSlots) {
+        if (bd->nrows == 0) { fits = false; break; }   // a single row needs more operands than LDS holds
+        ++bp.nblocks;
+        if (bp.nblocks >= (uint32_t)kMaxRows) { fits = false; break; }
+        open_block(r);
+        bd = &bp.blk[bp.nblocks];
+        add.clear();
+        for (uint32_t t = 0; t < row.nterms; ++t) add[{pb.p.terms[row.term0 + t].b_op, pb.p.terms[row.term0 + t].b_off}] = 0;
+        if (add.size() > (size_t)kBlockMaxSlots) { fits = false; break; }
+      }
+      for (auto& kv : add) {
+        if (bp.nslots_total >= (uint32_t)kMaxSlots) { fits = false; break; }
+        const uint32_t sidx = bd->nslots++;
+        cur[kv.first] = sidx;
+        bp.slot_op[bp.nslots_total] = (uint16_t)kv.first.first;
+        bp.slot_off[bp.nslots_total] = (uint16_t)kv.first.second;
+        ++bp.nslots_total;
+      }
+      for (uint32_t t = 0; fits && t < row.nterms; ++t) {
+        const Term& tm = pb.p.terms[row.term0 + t];
+        const uint32_t sidx = cur[{tm.b_op, tm.b_off}];
+        bp.term_slot[row.term0 + t] = (uint16_t)sidx;
+        if (tm.kind & TERM_CHECK) bp.slot_check[bd->slot0 + sidx] = 1;
+      }
+      bd->nrows++;
+    }
+    if (fits) {
+      ++bp.nblocks;
+      if (bp.nslots_total > 0 && (double)pb.p.nterms / bp.nslots_total >= 2.0) {
+        HIPCHK(c, hipMalloc((void**)&dp.d_blocks, sizeof(BlockPlan)));
+        HIPCHK(c, hipMemcpyAsync(dp.d_blocks, &bp, sizeof(BlockPlan), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        dp.nblocks = bp.nblocks;
+      }
+    }
+  }
+  if (!c->small && c->use_groups && !dp.shift && !dp.two_bit && !dp.nblocks) {
     bool key_only = pb.p.nterms > 0;
     for (uint32_t t = 0; t < pb.p.nterms; ++t) key_only = key_only && (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_KEY;
     if (key_only) {
@@ -554,7 +622,7 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
   // distinct operands of the product terms ("slots"); when rows share them often enough, transform each
   // once per proof (shared-operand path) instead of once per row
   if (!c->small && c->slot_share_min > 0 && pb.p.nterms > 0 && dp.ngroups == 0 && !dp.shift && !dp.has_shift &&
-      !dp.two_bit) {
+      !dp.two_bit && !dp.nblocks) {
     std::vector<SlotTable> stv(1);
     SlotTable& st = stv[0];
     std::memset(&st, 0, sizeof(st));
@@ -599,6 +667,7 @@ void drop_programs(rzk_ctx* c) {
   for (auto& kv : c->progs) {
     if (kv.second.d) (void)hipFree(kv.second.d);
     if (kv.second.d_slots) (void)hipFree(kv.second.d_slots);
+    if (kv.second.d_blocks) (void)hipFree(kv.second.d_blocks);
   }
   c->progs.clear();
 }
@@ -645,6 +714,11 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
     lrc = launch_row_program_small(c->N, cfg_of(c), dp.d, dp.nrows, ops, c->d_key_mont, c->dT, c->r2q, flags, batch);
   } else if (dp.shift) {
     lrc = launch_shift_rows((int)c->logn, cfg_of(c), dp.d, dp.nrows, ops, c->dT, flags, batch);
+  } else if (dp.nblocks) {
+    if (!c->d_block_scratch)
+      HIPCHK(c, hipMalloc((void**)&c->d_block_scratch, block_scratch_words((int)c->logn, c->num_cus) * sizeof(uint32_t)));
+    lrc = launch_row_blocks((int)c->logn, cfg_of(c), dp.d, dp.d_blocks, dp.nblocks, ops, c->d_key_ntt, c->d_key_inf, c->dT,
+                            c->d_tw, c->d_block_scratch, flags, batch);
   } else if (dp.ngroups) {
     if (!c->d_group_scratch)
       HIPCHK(c, hipMalloc((void**)&c->d_group_scratch, group_scratch_words((int)c->logn, c->num_cus) * sizeof(uint32_t)));
@@ -832,6 +906,7 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
     if (g >= 1 && g <= (c->logn >= 11 ? 2 : RZK_GROUP_GM)) c->group_max = g;   // bounded by the compiled accumulators
   }
   if (const char* e = std::getenv("RZK_SHIFT")) c->use_shift = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RZK_BLOCK_MIN_LOGN")) c->block_min_logn = (uint32_t)std::atoi(e);   // 12 = never
 
   // twiddle tables: 3 primes x {fwd, inv} x kTableLen
   std::vector<uint32_t> all((size_t)2 * kMaxPrimes * kTableLen);
@@ -875,6 +950,7 @@ void rzk_ctx_destroy(rzk_ctx* c) {
   if (c->dT) (void)hipFree(c->dT);
   if (c->d_tw) (void)hipFree(c->d_tw);
   if (c->d_row_scratch) (void)hipFree(c->d_row_scratch);
+  if (c->d_block_scratch) (void)hipFree(c->d_block_scratch);
   if (c->d_group_scratch) (void)hipFree(c->d_group_scratch);
   if (c->d_key_mont) (void)hipFree(c->d_key_mont);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -1125,7 +1201,9 @@ namespace {
 // units per (4,9,4) relation.
 int run_a1_relation(rzk_ctx* c, const std::vector<OpSpec>& specs, int64_t* w, uint8_t* accept, uint32_t group,
                     uint64_t batch, uint64_t nflags, bool preset) {
-  const bool split = w && shift_ok(c) && c->use_groups && c->group_max > 1 && c->n >= 2;
+  // (at N = 2048 the first step runs as row blocks and the second as transform products)
+  const bool blocks = !c->small && c->logn >= 10 && c->logn >= c->block_min_logn;
+  const bool split = w && c->n >= 2 && ((shift_ok(c) && c->use_groups && c->group_max > 1) || blocks);
   int rc;
   if (split) {
     const std::vector<OpSpec> a1z = {specs[0], {w, c->n, 0}};

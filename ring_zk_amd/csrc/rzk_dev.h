@@ -92,6 +92,24 @@ struct SlotTable {
   uint16_t term_a[kMaxTerms], term_b[kMaxTerms];
 };
 
+// Row blocks (row_block_kernel): consecutive rows of a key-only program whose distinct operands fit in LDS
+// together.  One 8-wave workgroup evaluates a block of one proof prime by prime: the waves transform the
+// block's operands into LDS (each exactly once), meet at a barrier, then every wave evaluates rows from the
+// staged transforms.  For [a1;a2].r at (8,17,8) that is 9 transforms per prime and block instead of 72 + 8.
+constexpr int kBlockWaves = 8;     // (9, one per staged operand, measured slightly slower)
+constexpr int kBlockMaxSlots = 9;    // staged operand transforms per block: 9 * 4N bytes of LDS (72 KiB at N = 2048)
+constexpr int kBlockMaxRows = 16;    // rows per block (two Garner state lines each in the workgroup's scratch)
+struct BlockDesc {
+  uint16_t row0, nrows, slot0, nslots;
+};
+struct BlockPlan {
+  uint32_t nblocks, nslots_total;
+  BlockDesc blk[kMaxRows];
+  uint16_t slot_op[kMaxSlots], slot_off[kMaxSlots];   // indexed by BlockDesc::slot0 + s
+  uint8_t slot_check[kMaxSlots];
+  uint16_t term_slot[kMaxTerms];                      // slot (within its block) of each term's operand
+};
+
 // Operand table of one launch.  The batch index b of a task may be a (proof, summand) pair:
 // bo = b / group is the proof.  Polynomial (op, off) lives at
 // base[op] + ((outer[op] ? bo : b) * stride[op] + off) * N ; verification flags are per proof (flags[bo]).
@@ -123,6 +141,10 @@ int launch_row_groups(int logn, const LaunchCfg& cfg, const Program* d_prog, uin
                       const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* d_T, const uint32_t* d_tw,
                       uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch);
 size_t group_scratch_words(int logn, int num_cus);
+int launch_row_blocks(int logn, const LaunchCfg& cfg, const Program* d_prog, const BlockPlan* d_plan, uint32_t nblocks,
+                      const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* d_T,
+                      const uint32_t* d_tw, uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch);
+size_t block_scratch_words(int logn, int num_cus);
 // rows whose products all have a sparse multiplier (the challenge) as `a` operand: shift-add kernel, no transforms
 int launch_shift_rows(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows, const Operands& ops,
                       const DevTables* d_T, uint8_t* d_flags, uint64_t batch);

@@ -760,6 +760,112 @@ row_group_kernel(const Program* __restrict__ prog, const Operands ops, const uin
   }
 }
 
+// ---- row blocks ---------------------------------------------------------------------------------------------
+// One workgroup of kBlockWaves wavefronts evaluates one block (rzk_dev.h: BlockPlan) of one proof.  Per prime:
+//   phase 1  wave w transforms operands w, w+8, ... of the block and leaves them in LDS ([c][lane] order:
+//            lane-consecutive words, conflict-free); the first prime also measures the operands' norms;
+//   barrier; phase 2  wave w evaluates rows w, w+8, ...: multiply-accumulate from the staged transforms and the
+//            resident key, inverse transform, fold into the row's Garner state (workgroup scratch in global
+//            memory); barrier before the next prime overwrites the staged transforms.
+// Every wave runs the same number of barriers: the prime count is the block's maximum, computed by every wave
+// from the same norms in LDS (more primes than a row needs is still exact).
+template <int LOGN>
+__global__ void __launch_bounds__(64 * kBlockWaves)
+row_block_kernel(const Program* __restrict__ prog, const BlockPlan* __restrict__ plan, const Operands ops,
+                 const uint32_t* __restrict__ key_ntt, const double* __restrict__ key_inf,
+                 const DevTables* __restrict__ Tp, const uint32_t* __restrict__ tw_all, uint32_t* __restrict__ scratch,
+                 uint8_t* __restrict__ flags, const uint32_t ntasks) {
+  using G = Geo<LOGN>;
+  constexpr int E = G::E;
+  constexpr int N = G::N;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t* staged = smem;                                                     // [kBlockMaxSlots][N]
+  uint32_t* lds = smem + kBlockMaxSlots * N + wave * G::LDS_WORDS;             // this wave's transposition slab
+  double* norm1 = reinterpret_cast<double*>(smem + kBlockMaxSlots * N + kBlockWaves * G::LDS_WORDS);   // [slots]
+  uint32_t* st = scratch + (size_t)blockIdx.x * (size_t)(2 * kBlockMaxRows) * N;   // [row][A|B][N]
+  const DevTables& T = *Tp;
+  const uint32_t nblocks = plan->nblocks;
+
+  for (uint32_t task = blockIdx.x; task < ntasks; task += gridDim.x) {
+    const uint32_t b = task / nblocks;
+    const BlockDesc bd = plan->blk[task - b * nblocks];
+    const uint32_t bo = ops.group > 1 ? b / ops.group : b;
+    int np = kMaxPrimes;
+#pragma unroll 1
+    for (int pi = 0; pi < np; ++pi) {
+      const PrimeConsts pc = T.pc[pi];
+      const uint32_t* __restrict__ twf = tw_all + (size_t)(2 * pi) * kTableLen;
+      const bool first = pi == 0;
+      // ---- phase 1: operand transforms into LDS
+#pragma unroll 1
+      for (uint32_t s = wave; s < bd.nslots; s += kBlockWaves) {
+        const uint32_t gs = bd.slot0 + s;
+        uint32_t x[E];
+        double l1 = 0, linf = 0;
+        uint64_t sumsq = 0;
+        const bool chk = first && plan->slot_check[gs] && ops.norm_limit;
+        load_lift<LOGN>(x, operand_ptr(ops, plan->slot_op[gs], plan->slot_off[gs], b, bo, N), lane, pc, first, l1, linf,
+                        chk, sumsq);
+        if (chk && sumsq >= ops.norm_limit && lane == 0) flags[bo] = 0;
+        if (first && lane == 0) norm1[s] = l1;
+        wave_fwd<LOGN>(x, lane, lds, twf, pc);
+        uint32_t* dst = staged + s * N + lane;
+#pragma unroll
+        for (int c = 0; c < E; ++c) dst[c * 64] = x[c];
+      }
+      __syncthreads();
+      if (first) {
+        double mx = 0.0;
+#pragma unroll 1
+        for (uint32_t r = 0; r < bd.nrows; ++r) {
+          const Row row = prog->rows[bd.row0 + r];
+          double bound = 0.0;
+#pragma unroll 1
+          for (uint32_t t = 0; t < row.nterms; ++t)
+            bound += key_inf[prog->terms[row.term0 + t].a_off] * norm1[plan->term_slot[row.term0 + t]];
+          mx = bound > mx ? bound : mx;
+        }
+        np = primes_for(mx, T);
+      }
+      // ---- phase 2: rows from the staged transforms
+#pragma unroll 1
+      for (uint32_t r = wave; r < bd.nrows; r += kBlockWaves) {
+        const Row row = prog->rows[bd.row0 + r];
+        if (row.nterms == 0) continue;
+        uint32_t acc[E];
+#pragma unroll
+        for (int c = 0; c < E; ++c) acc[c] = 0;
+#pragma unroll 1
+        for (uint32_t t = 0; t < row.nterms; ++t) {
+          const Term tm = prog->terms[row.term0 + t];
+          const uint32_t* __restrict__ xs = staged + (size_t)plan->term_slot[row.term0 + t] * N + lane;
+          const uint4* __restrict__ kp = reinterpret_cast<const uint4*>(key_ntt + ((size_t)tm.a_off * kMaxPrimes + pi) * N);
+#pragma unroll
+          for (int g = 0; g < E / 4; ++g) {
+            const uint4 kv = kp[g * 64 + lane];
+            const uint32_t ks[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const uint32_t xv = xs[(4 * g + i) * 64];
+              acc[4 * g + i] = tm.sign >= 0 ? mac_add(acc[4 * g + i], xv, ks[i], pc) : mac_sub(acc[4 * g + i], xv, ks[i], pc);
+            }
+          }
+        }
+        inverse_and_fold<LOGN>(pi, np, acc, lane, lds, twf + kTableLen, pc, st + (size_t)(2 * r) * N,
+                               st + (size_t)(2 * r + 1) * N, T);
+      }
+      __syncthreads();   // the staged transforms are overwritten by the next prime / next task
+    }
+#pragma unroll 1
+    for (uint32_t r = wave; r < bd.nrows; r += kBlockWaves) {
+      const Row row = prog->rows[bd.row0 + r];
+      row_epilogue<LOGN>(prog, row, ops, b, bo, lane, row.nterms > 0, np, st + (size_t)(2 * r) * N, T, flags);
+    }
+  }
+}
+
 // ---- shared-operand path ------------------------------------------------------------------------------------
 // Forward pass: one wavefront per (proof, slot) transforms the slot's polynomial for the first `np_store`
 // primes into ws[((b*nslots + s)*np_store + pi)*N ...] (canonical residues, NTT-domain layout) and records
@@ -1473,6 +1579,44 @@ int launch_row_groups(int logn, const LaunchCfg& cfg, const Program* d_prog, uin
     case 9: return launch_groups_t<9>(cfg, d_prog, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
     case 10: return launch_groups_t<10>(cfg, d_prog, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
     case 11: return launch_groups_t<11>(cfg, d_prog, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
+  }
+  return -1;
+}
+
+size_t block_scratch_words(int logn, int num_cus) {
+  return (size_t)num_cus * 2 * (size_t)(2 * kBlockMaxRows) * ((size_t)1 << logn);
+}
+
+template <int LOGN>
+static int launch_blocks_t(const LaunchCfg& cfg, const Program* d_prog, const BlockPlan* d_plan, const Operands& ops,
+                           const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T, const uint32_t* d_tw,
+                           uint32_t* d_scratch, uint8_t* d_flags, uint32_t ntasks) {
+  using G = Geo<LOGN>;
+  const size_t lds = ((size_t)kBlockMaxSlots * G::N + (size_t)kBlockWaves * G::LDS_WORDS) * sizeof(uint32_t) +
+                     kBlockMaxSlots * sizeof(double);
+  static bool attr_set = false;   // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&row_block_kernel<LOGN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  uint32_t grid = ntasks < (uint32_t)cfg.num_cus * 2 ? ntasks : (uint32_t)cfg.num_cus * 2;   // scratch: num_cus * 2 lines
+  hipLaunchKernelGGL((row_block_kernel<LOGN>), dim3(grid), dim3(64 * kBlockWaves), lds, (hipStream_t)cfg.stream, d_prog,
+                     d_plan, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_row_blocks(int logn, const LaunchCfg& cfg, const Program* d_prog, const BlockPlan* d_plan, uint32_t nblocks,
+                      const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T,
+                      const uint32_t* d_tw, uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch) {
+  if (batch == 0 || nblocks == 0) return 0;
+  if (batch * nblocks >= (1ull << 32)) return -2;
+  const uint32_t ntasks = (uint32_t)(batch * nblocks);
+  switch (logn) {
+    case 10: return launch_blocks_t<10>(cfg, d_prog, d_plan, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
+    case 11: return launch_blocks_t<11>(cfg, d_prog, d_plan, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
   }
   return -1;
 }

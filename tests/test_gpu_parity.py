@@ -549,3 +549,55 @@ def test_linear_commit_two_bit_verdicts(torch_mod, N):
     # a batch that is not a multiple of 4 takes the separate norm kernels: same verdicts
     out = ctx.linear_commit(g[:7], x[:7], r[:7], rp[:7], y[:7], yp[:7])
     assert out[5].tolist() == want_ok[:7]
+
+
+# ---- row blocks (operands of a block staged once in LDS, 8-wave workgroups) ----------------------------------
+@pytest.mark.parametrize("N", [1024, 2048])
+def test_row_blocks_vs_oracle(torch_mod, N, monkeypatch):
+    """Key-only programs on the row-block kernel (default from N = 2048 on; forced at N = 1024 here): commit,
+    matrix-vector products, commitment verification and the two-step A1 relation, bit-exact against the oracle,
+    including a failing norm predicate and a batch larger than the resident grid would need."""
+    from ring_zk_amd import Context
+
+    monkeypatch.setenv("RZK_BLOCK_MIN_LOGN", "10")
+    n, k, l = 2, 5, 2
+    ctx = Context(N, n, k, l)                       # fresh context: the knob is read at creation
+    P = _P(ctx)
+    rng = np.random.default_rng(5150 + N)
+    A = synth.key(rng, N, n, k, l)
+    ctx.load_key(A)
+    B = 4
+    x = synth.uniform(rng, (B, l, N))
+    r = synth.small(rng, (B, k, N))
+    y = synth.gauss(rng, (B, k, N), P.sigma)
+    d = synth.challenge(rng, (B,), N, P.kappa)
+    r[2, k - 1] = synth.uniform(rng, (N,))          # commit constraint fails for proof 2
+    c, t, ok = ctx.open_commit(x, r, y)
+    for b in range(B):
+        c_ref, t_ref, ok_ref = O.open_commit(P, A, x[b], r[b], y[b])
+        assert np.array_equal(c[b], c_ref) and np.array_equal(t[b], t_ref) and bool(ok[b]) == ok_ref
+    assert ok.tolist() == [1, 1, 0, 1]
+    for which, rows in ((0, slice(0, n)), (1, slice(n, n + l)), (2, slice(0, n + l))):
+        got = ctx.matvec(which, y)
+        for b in range(B):
+            assert np.array_equal(got[b], O.mat_dot(A[rows], y[b][:, None, :])[:, 0, :])
+    cm, okc = ctx.commit(x, r)
+    assert np.array_equal(cm, c) and okc.tolist() == ok.tolist()
+    assert ctx.commitment_verify(c, x, r).tolist() == [1, 1, 0, 1]
+    z = ctx.open_response(y, r, d)
+    zt = z.copy()
+    zt[1, 0, 3] = O.center(int(zt[1, 0, 3]) + 1)
+    acc = ctx.open_verify(zt, t, c, d)
+    for b in range(B):
+        assert np.array_equal(z[b], O.open_response(P, y[b], r[b], d[b]))
+        assert int(acc[b]) == int(O.open_verify(P, A, zt[b], t[b], c[b], d[b]) == 1)
+    assert acc.tolist()[0] == 1 and acc.tolist()[1] == 0
+    # many proofs: more tasks than resident workgroups, every proof checked through a size-independent property
+    Bb = 700
+    yb = synth.gauss(rng, (Bb, k, N), P.sigma)
+    t1 = ctx.matvec(0, yb)
+    t2 = ctx.matvec(0, 2 * yb)                      # linearity: a1.(2y) = 2 (a1.y) mod q
+    twice = (2 * t1.astype(object)) % Q
+    twice = np.where(twice > HALF, twice - Q, twice).astype(np.int64)
+    assert np.array_equal(t2, twice)
+    assert np.array_equal(t1[-1], O.mat_dot(A[:n], yb[-1][:, None, :])[:, 0, :])

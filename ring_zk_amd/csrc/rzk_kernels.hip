@@ -482,8 +482,14 @@ __device__ __forceinline__ int primes_for(double bound, const DevTables& T) {
   return __builtin_amdgcn_readfirstlane(np);
 }
 
+#ifndef RZK_ROW_WPB
+#define RZK_ROW_WPB 4        // wavefronts per workgroup of row_kernel
+#endif
+#ifndef RZK_ROW_OPAQUE
+#define RZK_ROW_OPAQUE 0     // 1: opaque lane ids in every row_kernel variant (not only the ones with rotation terms)
+#endif
 template <int LOGN, bool HAS_VEC, bool HAS_SHIFT>
-__global__ void __launch_bounds__(256, RZK_ROW_MIN_WAVES)
+__global__ void __launch_bounds__(64 * RZK_ROW_WPB, RZK_ROW_MIN_WAVES)
 row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t* __restrict__ key_ntt,
            const double* __restrict__ key_inf, const DevTables* __restrict__ Tp,
            const uint32_t* __restrict__ tw_all, uint32_t* __restrict__ scratch, uint8_t* __restrict__ flags,
@@ -498,12 +504,12 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
   // the 2N-word image of a shift term, which is finished before the transforms start
   uint32_t* lds = smem + wave * (G::LDS_WORDS + N);
   uint32_t* st_lds = lds + G::LDS_WORDS;
-  uint32_t* st_glb = scratch + ((size_t)blockIdx.x * 4 + wave) * (2 * N);   // state B, only touched when np == 3
+  uint32_t* st_glb = scratch + ((size_t)blockIdx.x * RZK_ROW_WPB + wave) * (2 * N);   // state B, only touched when np == 3
   uint32_t* st_sh = st_glb + N;                                             // sum of the row's shift terms mod q
   const DevTables& T = *Tp;
   const uint32_t nrows = prog->nrows;
 
-  for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
+  for (uint32_t task = blockIdx.x * RZK_ROW_WPB + wave; task < ntasks; task += gridDim.x * RZK_ROW_WPB) {
     const uint32_t b = task / nrows;
     const uint32_t rowi = task - b * nrows;
     const uint32_t bo = ops.group > 1 ? b / ops.group : b;
@@ -540,10 +546,10 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
         for (int c = 0; c < E; ++c) acc[c] = 0;
 #pragma unroll 1
         for (uint32_t t = 0; t < row.nterms; ++t)
-          term_direct<LOGN, HAS_VEC, HAS_SHIFT>(acc, prog->terms[row.term0 + t], ops, b, bo, lane, lds, twf, pc, pi, key_ntt,
+          term_direct<LOGN, HAS_VEC, HAS_SHIFT || RZK_ROW_OPAQUE>(acc, prog->terms[row.term0 + t], ops, b, bo, lane, lds, twf, pc, pi, key_ntt,
                                      key_inf, first, bound, flags);
         if (first) np = primes_for(bound, T);
-        inverse_and_fold<LOGN, HAS_SHIFT>(pi, np, acc, lane, lds, twf + kTableLen, pc, st_lds, st_glb, T);
+        inverse_and_fold<LOGN, HAS_SHIFT || RZK_ROW_OPAQUE>(pi, np, acc, lane, lds, twf + kTableLen, pc, st_lds, st_glb, T);
       }
     }
     row_epilogue<LOGN>(prog, row, ops, b, bo, lane, has_terms, np, st_lds, T, flags, has_shift ? st_sh : nullptr);
@@ -1494,9 +1500,9 @@ static int launch_row_t(const LaunchCfg& cfg, const Program* d_prog, const Opera
                         const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T,
                         const uint32_t* d_tw, uint32_t* d_scratch, uint8_t* d_flags, uint32_t ntasks) {
   using G = Geo<LOGN>;
-  const size_t lds = 4 * (G::LDS_WORDS + G::N) * sizeof(uint32_t);   // transposition slab + Garner state per wave
-  const unsigned grid = grid_for(ntasks, cfg.num_cus);               // <= num_cus * 8 blocks (scratch sizing)
-  hipLaunchKernelGGL((row_kernel<LOGN, HAS_VEC, HAS_SHIFT>), dim3(grid), dim3(256), lds, (hipStream_t)cfg.stream, d_prog,
+  const size_t lds = RZK_ROW_WPB * (G::LDS_WORDS + G::N) * sizeof(uint32_t);   // transposition slab + Garner state per wave
+  const unsigned grid = grid_for(ntasks, cfg.num_cus, RZK_ROW_WPB, 8);         // <= num_cus * 8 blocks (scratch sizing)
+  hipLaunchKernelGGL((row_kernel<LOGN, HAS_VEC, HAS_SHIFT>), dim3(grid), dim3(64 * RZK_ROW_WPB), lds, (hipStream_t)cfg.stream, d_prog,
                      ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
   RZK_LAUNCH_CHECK();
   return 0;

@@ -601,3 +601,37 @@ def test_row_blocks_vs_oracle(torch_mod, N, monkeypatch):
     twice = np.where(twice > HALF, twice - Q, twice).astype(np.int64)
     assert np.array_equal(t2, twice)
     assert np.array_equal(t1[-1], O.mat_dot(A[:n], yb[-1][:, None, :])[:, 0, :])
+
+
+def test_device_buffers_at_8_byte_alignment(torch_mod):
+    """The C ABI takes int64*: device buffers need no more than 8-byte alignment, although the rotation kernel
+    and the stores use 16-byte accesses (global memory on this target tolerates them unaligned)."""
+    N, n, k, l = 1024, 1, 3, 1
+    ctx = ctx_for(N, n, k, l)
+    P = _P(ctx)
+    rng = np.random.default_rng(1234)
+    A = synth.key(rng, N, n, k, l)
+    ctx.load_key(A)
+    B = 3
+    x = synth.uniform(rng, (B, l, N))
+    r = synth.small(rng, (B, k, N))
+    y = synth.gauss(rng, (B, k, N), P.sigma)
+    d = synth.challenge(rng, (B,), N, P.kappa)
+
+    def odd(a):
+        """copy of `a` on the device that starts one int64 past a 256-byte aligned allocation"""
+        buf = torch_mod.empty(a.size + 1, dtype=torch_mod.int64, device="cuda")
+        view = buf[1:].view(a.shape)
+        view.copy_(torch_mod.from_numpy(a))
+        assert view.data_ptr() % 16 == 8 and view.is_contiguous()
+        return view
+
+    c, t, ok = ctx.open_commit(odd(x), odd(r), odd(y))
+    z = ctx.open_response(odd(y), odd(r), odd(d))
+    zo = odd(z.cpu().numpy())
+    acc = ctx.open_verify(zo, odd(t.cpu().numpy()), odd(c.cpu().numpy()), odd(d))
+    for b in range(B):
+        c_ref, t_ref, _ = O.open_commit(P, A, x[b], r[b], y[b])
+        assert np.array_equal(c[b].cpu().numpy(), c_ref) and np.array_equal(t[b].cpu().numpy(), t_ref)
+        assert np.array_equal(z[b].cpu().numpy(), O.open_response(P, y[b], r[b], d[b]))
+    assert acc.cpu().numpy().tolist() == [1] * B

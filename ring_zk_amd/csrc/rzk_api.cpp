@@ -1109,11 +1109,13 @@ int rzk_key_load_dev(rzk_ctx* c, const int64_t* a_dev) {
 // ring / Mat primitives
 // =================================================================================================
 int rzk_polymul_batch_dev(rzk_ctx* c, const int64_t* a, const int64_t* b, int64_t* out, size_t count) {
+  if (c && count == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !a || !b || !out) return RZK_E_ARG;
   return run_program(c, PG_POLYMUL, 0, {{a, 1, 0}, {b, 1, 0}, {out, 1, 0}}, nullptr, 1, count);
 }
 
 int rzk_matvec_batch_dev(rzk_ctx* c, int which, const int64_t* v, const int64_t* addend, int64_t* out, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !v || !out || which < 0 || which > 2) return RZK_E_ARG;
   const uint32_t rows = which == RZK_KEY_A1 ? c->n : (which == RZK_KEY_A2 ? c->l : c->n + c->l);
   return run_program(c, PG_MATVEC, (uint32_t)which * 2 + (addend ? 1 : 0),
@@ -1121,6 +1123,7 @@ int rzk_matvec_batch_dev(rzk_ctx* c, int which, const int64_t* v, const int64_t*
 }
 
 int rzk_cmul_batch_dev(rzk_ctx* c, const int64_t* m, uint32_t rows, const int64_t* p, int64_t* out, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !m || !p || !out || rows == 0) return RZK_E_ARG;
   if (rows > (uint32_t)kMaxRows) {
     // more rows than one program holds: treat every row as its own batch entry sharing p
@@ -1130,33 +1133,39 @@ int rzk_cmul_batch_dev(rzk_ctx* c, const int64_t* m, uint32_t rows, const int64_
 }
 
 int rzk_add_batch_dev(rzk_ctx* c, const int64_t* a, const int64_t* b, int64_t* out, size_t count) {
+  if (c && count == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !a || !b || !out) return RZK_E_ARG;
   return check_launch(c, launch_addsub(cfg_of(c), false, a, b, out, (uint64_t)count * c->N, c->dT), "add kernel");
 }
 
 int rzk_sub_batch_dev(rzk_ctx* c, const int64_t* a, const int64_t* b, int64_t* out, size_t count) {
+  if (c && count == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !a || !b || !out) return RZK_E_ARG;
   return check_launch(c, launch_addsub(cfg_of(c), true, a, b, out, (uint64_t)count * c->N, c->dT), "sub kernel");
 }
 
 int rzk_norm2_le_batch_dev(rzk_ctx* c, const int64_t* v, uint32_t rows, uint64_t bound, uint8_t* ok, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !v || !ok || rows == 0) return RZK_E_ARG;
   return run_norm(c, v, rows, bound, ok, B, 0, 0);
 }
 
 int rzk_eq_batch_dev(rzk_ctx* c, const int64_t* a, const int64_t* b, uint32_t rows, uint8_t* eq, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !a || !b || !eq || rows == 0) return RZK_E_ARG;
   if (c->small) return check_launch(c, launch_eq_small(c->N, cfg_of(c), a, b, rows, eq, B), "eq kernel");
   return check_launch(c, launch_eq((int)c->logn, cfg_of(c), a, b, rows, eq, B), "eq kernel");
 }
 
 int rzk_ntt_forward_batch_dev(rzk_ctx* c, int prime, const uint32_t* in, uint32_t* out, size_t count) {
+  if (c && count == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !in || !out || prime < 0 || prime >= kMaxPrimes) return RZK_E_ARG;
   if (c->small) return fail(c, RZK_E_UNSUPPORTED, "batched transforms need N >= 512");
   return check_launch(c, launch_ntt((int)c->logn, false, cfg_of(c), prime, in, out, count, c->dT, c->d_tw), "ntt forward");
 }
 
 int rzk_ntt_inverse_batch_dev(rzk_ctx* c, int prime, const uint32_t* in, uint32_t* out, size_t count) {
+  if (c && count == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !in || !out || prime < 0 || prime >= kMaxPrimes) return RZK_E_ARG;
   if (c->small) return fail(c, RZK_E_UNSUPPORTED, "batched transforms need N >= 512");
   return check_launch(c, launch_ntt((int)c->logn, true, cfg_of(c), prime, in, out, count, c->dT, c->d_tw), "ntt inverse");
@@ -1178,15 +1187,18 @@ uint32_t rzk_ntt_layout_index(uint32_t N, uint32_t j) {
 // Device-side samplers
 // =================================================================================================
 int rzk_sample_uniform_dev(rzk_ctx* c, uint64_t seed, uint32_t stream, uint64_t bound, int64_t* out, size_t count) {
+  if (c && count == 0) return RZK_OK;
   if (!c || !out || bound == 0 || bound > (uint64_t)(c->q - 1) / 2) return RZK_E_ARG;
   return check_launch(c, launch_sample_uniform(cfg_of(c), out, count, c->N, seed, stream, (uint32_t)bound), "sampler");
 }
 int rzk_sample_gauss_dev(rzk_ctx* c, uint64_t seed, uint32_t stream, double sigma, int64_t* out, size_t count) {
+  if (c && count == 0) return RZK_OK;
   // |x| stays far below (q-1)/2 for every sigma the parameters produce; 2^26 keeps 12 sigma inside the range
   if (!c || !out || !(sigma > 0.0) || sigma > 67108864.0) return RZK_E_ARG;
   return check_launch(c, launch_sample_gauss(cfg_of(c), out, count, c->N, seed, stream, sigma), "sampler");
 }
 int rzk_sample_challenge_dev(rzk_ctx* c, uint64_t seed, uint32_t stream, int64_t* out, size_t count) {
+  if (c && count == 0) return RZK_OK;
   if (!c || !out) return RZK_E_ARG;
   return check_launch(c, launch_sample_challenge(cfg_of(c), out, count, c->N, seed, stream, c->kappa), "sampler");
 }
@@ -1229,6 +1241,7 @@ int run_a1_relation(rzk_ctx* c, const std::vector<OpSpec>& specs, int64_t* w, ui
 // Commitment scheme
 // =================================================================================================
 int rzk_commit_batch_dev(rzk_ctx* c, const int64_t* x, const int64_t* r, int64_t* cm, uint8_t* ok, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !x || !r || !cm) return RZK_E_ARG;
   const std::vector<OpSpec> specs = {{x, c->l, 0}, {r, c->k, 0}, {cm, c->n + c->l, 0}};
   int rc = run_program_checked(c, PG_COMMIT, 0, specs, ok, 1, B, B, c->commit_bound);
@@ -1241,6 +1254,7 @@ int rzk_commit_batch_dev(rzk_ctx* c, const int64_t* x, const int64_t* r, int64_t
 
 int rzk_commitment_verify_batch_dev(rzk_ctx* c, const int64_t* cm, const int64_t* x, const int64_t* r,
                                     const int64_t* f, uint8_t* ok, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !cm || !x || !r || !ok) return RZK_E_ARG;
   const uint32_t var = f ? 2u : 0u;
   const std::vector<OpSpec> specs = {{x, c->l, 0}, {r, c->k, 0}, {cm, c->n + c->l, 0}, {f, 1, 0}};
@@ -1257,6 +1271,7 @@ int rzk_commitment_verify_batch_dev(rzk_ctx* c, const int64_t* cm, const int64_t
 // =================================================================================================
 int rzk_open_commit_batch_dev(rzk_ctx* c, const int64_t* x, const int64_t* r, const int64_t* y, int64_t* cm,
                               int64_t* t, uint8_t* ok, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !x || !r || !y || !cm || !t) return RZK_E_ARG;
   const std::vector<OpSpec> specs = {{x, c->l, 0}, {r, c->k, 0}, {y, c->k, 0}, {cm, c->n + c->l, 0}, {t, c->n, 0}};
   // check_commit_constraint(r) (params.rs:102-108) rides on the loads of r the commit rows do anyway
@@ -1270,12 +1285,14 @@ int rzk_open_commit_batch_dev(rzk_ctx* c, const int64_t* x, const int64_t* r, co
 
 int rzk_open_response_batch_dev(rzk_ctx* c, const int64_t* y, const int64_t* r, const int64_t* d, int64_t* z,
                                 size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !y || !r || !d || !z) return RZK_E_ARG;
   return run_program(c, PG_RESPONSE, 1, {{d, 1, 0}, {y, c->k, 0}, {r, c->k, 0}, {z, c->k, 0}}, nullptr, 1, B);
 }
 
 int rzk_open_verify_batch_dev(rzk_ctx* c, const int64_t* z, const int64_t* t, const int64_t* cm, const int64_t* d,
                               uint8_t* accept, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !z || !t || !cm || !d || !accept) return RZK_E_ARG;
   if (c->n != c->l) return fail(c, RZK_E_ARG, "c1_c2 split needs n == l (reference panics in Mat::add)");
   const std::vector<OpSpec> specs = {{z, c->k, 0}, {t, c->n, 0}, {cm, c->n + c->l, 0}, {d, 1, 0}};
@@ -1291,6 +1308,7 @@ int rzk_open_verify_batch_dev(rzk_ctx* c, const int64_t* z, const int64_t* t, co
 int rzk_linear_commit_batch_dev(rzk_ctx* c, const int64_t* g, const int64_t* x, const int64_t* r, const int64_t* rp,
                                 const int64_t* y, const int64_t* yp, int64_t* cm, int64_t* cpm, int64_t* t,
                                 int64_t* tp, int64_t* u, uint8_t* ok, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !g || !x || !r || !rp || !y || !yp || !cm || !cpm || !t || !tp || !u) return RZK_E_ARG;
   const uint32_t n = c->n, k = c->k, l = c->l;
   int rc = arena_reserve(c, c->ws, polys(c, 2 * B * l));
@@ -1325,6 +1343,7 @@ int rzk_linear_commit_batch_dev(rzk_ctx* c, const int64_t* g, const int64_t* x, 
 
 int rzk_linear_response_batch_dev(rzk_ctx* c, const int64_t* y, const int64_t* yp, const int64_t* r,
                                   const int64_t* rp, const int64_t* d, int64_t* z, int64_t* zp, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !y || !yp || !r || !rp || !d || !z || !zp) return RZK_E_ARG;
   const uint32_t k = c->k;
   return run_program(c, PG_RESPONSE, 2, {{d, 1, 0}, {y, k, 0}, {r, k, 0}, {z, k, 0}, {yp, k, 0}, {rp, k, 0}, {zp, k, 0}},
@@ -1334,6 +1353,7 @@ int rzk_linear_response_batch_dev(rzk_ctx* c, const int64_t* y, const int64_t* y
 int rzk_linear_verify_batch_dev(rzk_ctx* c, const int64_t* z, const int64_t* zp, const int64_t* cm,
                                 const int64_t* cpm, const int64_t* g, const int64_t* t, const int64_t* tp,
                                 const int64_t* u, const int64_t* d, uint8_t* accept, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !z || !zp || !cm || !cpm || !g || !t || !tp || !u || !d || !accept) return RZK_E_ARG;
   if (c->n != c->l) return fail(c, RZK_E_ARG, "c1_c2 split needs n == l (reference panics in Mat::add)");
   const uint32_t n = c->n, k = c->k, l = c->l;
@@ -1362,6 +1382,7 @@ int rzk_linear_verify_batch_dev(rzk_ctx* c, const int64_t* z, const int64_t* zp,
 int rzk_sum_commit_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* gs, const int64_t* xs, const int64_t* rs,
                              const int64_t* rp, const int64_t* ys, const int64_t* yp, int64_t* cs, int64_t* cpm,
                              int64_t* ts, int64_t* tp, int64_t* u, uint8_t* ok, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || V == 0 || !gs || !xs || !rs || !rp || !ys || !yp || !cs || !cpm || !ts || !tp || !u) return RZK_E_ARG;
   const uint32_t n = c->n, k = c->k, l = c->l;
   int rc = arena_reserve(c, c->ws, polys(c, B * l + B * V * l));
@@ -1403,6 +1424,7 @@ int rzk_sum_commit_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* gs, const in
 
 int rzk_sum_response_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* ys, const int64_t* yp, const int64_t* rs,
                                const int64_t* rp, const int64_t* d, int64_t* zs, int64_t* zp, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || V == 0 || !ys || !yp || !rs || !rp || !d || !zs || !zp) return RZK_E_ARG;
   const uint32_t k = c->k;
   // sum.rs:188-193: z_i = y_i + r_i (.) d — summands as batch entries, d shared by the V entries of a proof
@@ -1415,6 +1437,7 @@ int rzk_sum_response_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* ys, const 
 int rzk_sum_verify_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* zs, const int64_t* zp, const int64_t* cs,
                              const int64_t* cpm, const int64_t* gs, const int64_t* ts, const int64_t* tp,
                              const int64_t* u, const int64_t* d, uint8_t* accept, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || V == 0 || !zs || !zp || !cs || !cpm || !gs || !ts || !tp || !u || !d || !accept) return RZK_E_ARG;
   if (c->n != c->l) return fail(c, RZK_E_ARG, "c1_c2 split needs n == l (reference panics in Mat::add)");
   const uint32_t n = c->n, k = c->k, l = c->l;
@@ -1456,12 +1479,14 @@ int rzk_sum_verify_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* zs, const in
   } while (0)
 
 int rzk_polymul_batch(rzk_ctx* c, const int64_t* a, const int64_t* b, int64_t* out, size_t count) {
+  if (c && count == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !a || !b || !out) return RZK_E_ARG;
   std::vector<HostBuf> bufs = {IN(a, polys(c, count)), IN(b, polys(c, count)), OUT(out, polys(c, count))};
   HOST_WRAP(rzk_polymul_batch_dev(c, DEV(0, const int64_t*), DEV(1, const int64_t*), DEV(2, int64_t*), count));
 }
 
 int rzk_matvec_batch(rzk_ctx* c, int which, const int64_t* v, const int64_t* addend, int64_t* out, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !v || !out || which < 0 || which > 2) return RZK_E_ARG;
   const uint32_t rows = which == RZK_KEY_A1 ? c->n : (which == RZK_KEY_A2 ? c->l : c->n + c->l);
   std::vector<HostBuf> bufs = {IN(v, polys(c, B * c->k)), IN(addend, addend ? polys(c, B * rows) : 0),
@@ -1471,36 +1496,42 @@ int rzk_matvec_batch(rzk_ctx* c, int which, const int64_t* v, const int64_t* add
 }
 
 int rzk_cmul_batch(rzk_ctx* c, const int64_t* m, uint32_t rows, const int64_t* p, int64_t* out, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !m || !p || !out || rows == 0) return RZK_E_ARG;
   std::vector<HostBuf> bufs = {IN(m, polys(c, B * rows)), IN(p, polys(c, B)), OUT(out, polys(c, B * rows))};
   HOST_WRAP(rzk_cmul_batch_dev(c, DEV(0, const int64_t*), rows, DEV(1, const int64_t*), DEV(2, int64_t*), B));
 }
 
 int rzk_add_batch(rzk_ctx* c, const int64_t* a, const int64_t* b, int64_t* out, size_t count) {
+  if (c && count == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !a || !b || !out) return RZK_E_ARG;
   std::vector<HostBuf> bufs = {IN(a, polys(c, count)), IN(b, polys(c, count)), OUT(out, polys(c, count))};
   HOST_WRAP(rzk_add_batch_dev(c, DEV(0, const int64_t*), DEV(1, const int64_t*), DEV(2, int64_t*), count));
 }
 
 int rzk_sub_batch(rzk_ctx* c, const int64_t* a, const int64_t* b, int64_t* out, size_t count) {
+  if (c && count == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !a || !b || !out) return RZK_E_ARG;
   std::vector<HostBuf> bufs = {IN(a, polys(c, count)), IN(b, polys(c, count)), OUT(out, polys(c, count))};
   HOST_WRAP(rzk_sub_batch_dev(c, DEV(0, const int64_t*), DEV(1, const int64_t*), DEV(2, int64_t*), count));
 }
 
 int rzk_norm2_le_batch(rzk_ctx* c, const int64_t* v, uint32_t rows, uint64_t bound, uint8_t* ok, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !v || !ok || rows == 0) return RZK_E_ARG;
   std::vector<HostBuf> bufs = {IN(v, polys(c, B * rows)), OUT(ok, B)};
   HOST_WRAP(rzk_norm2_le_batch_dev(c, DEV(0, const int64_t*), rows, bound, DEV(1, uint8_t*), B));
 }
 
 int rzk_eq_batch(rzk_ctx* c, const int64_t* a, const int64_t* b, uint32_t rows, uint8_t* eq, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !a || !b || !eq || rows == 0) return RZK_E_ARG;
   std::vector<HostBuf> bufs = {IN(a, polys(c, B * rows)), IN(b, polys(c, B * rows)), OUT(eq, B)};
   HOST_WRAP(rzk_eq_batch_dev(c, DEV(0, const int64_t*), DEV(1, const int64_t*), rows, DEV(2, uint8_t*), B));
 }
 
 int rzk_ntt_forward_batch(rzk_ctx* c, int prime, const uint32_t* in, uint32_t* out, size_t count) {
+  if (c && count == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !in || !out) return RZK_E_ARG;
   const size_t bytes = count * c->N * sizeof(uint32_t);
   std::vector<HostBuf> bufs = {IN(in, bytes), OUT(out, bytes)};
@@ -1508,6 +1539,7 @@ int rzk_ntt_forward_batch(rzk_ctx* c, int prime, const uint32_t* in, uint32_t* o
 }
 
 int rzk_ntt_inverse_batch(rzk_ctx* c, int prime, const uint32_t* in, uint32_t* out, size_t count) {
+  if (c && count == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !in || !out) return RZK_E_ARG;
   const size_t bytes = count * c->N * sizeof(uint32_t);
   std::vector<HostBuf> bufs = {IN(in, bytes), OUT(out, bytes)};
@@ -1515,6 +1547,7 @@ int rzk_ntt_inverse_batch(rzk_ctx* c, int prime, const uint32_t* in, uint32_t* o
 }
 
 int rzk_commit_batch(rzk_ctx* c, const int64_t* x, const int64_t* r, int64_t* cm, uint8_t* ok, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !x || !r || !cm) return RZK_E_ARG;
   std::vector<HostBuf> bufs = {IN(x, polys(c, B * c->l)), IN(r, polys(c, B * c->k)),
                                OUT(cm, polys(c, B * (c->n + c->l))), OUT(ok, ok ? B : 0)};
@@ -1524,6 +1557,7 @@ int rzk_commit_batch(rzk_ctx* c, const int64_t* x, const int64_t* r, int64_t* cm
 
 int rzk_commitment_verify_batch(rzk_ctx* c, const int64_t* cm, const int64_t* x, const int64_t* r, const int64_t* f,
                                 uint8_t* ok, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !cm || !x || !r || !ok) return RZK_E_ARG;
   std::vector<HostBuf> bufs = {IN(cm, polys(c, B * (c->n + c->l))), IN(x, polys(c, B * c->l)),
                                IN(r, polys(c, B * c->k)), IN(f, f ? polys(c, B) : 0), OUT(ok, B)};
@@ -1533,6 +1567,7 @@ int rzk_commitment_verify_batch(rzk_ctx* c, const int64_t* cm, const int64_t* x,
 
 int rzk_open_commit_batch(rzk_ctx* c, const int64_t* x, const int64_t* r, const int64_t* y, int64_t* cm, int64_t* t,
                           uint8_t* ok, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !x || !r || !y || !cm || !t) return RZK_E_ARG;
   std::vector<HostBuf> bufs = {IN(x, polys(c, B * c->l)), IN(r, polys(c, B * c->k)), IN(y, polys(c, B * c->k)),
                                OUT(cm, polys(c, B * (c->n + c->l))), OUT(t, polys(c, B * c->n)), OUT(ok, ok ? B : 0)};
@@ -1541,6 +1576,7 @@ int rzk_open_commit_batch(rzk_ctx* c, const int64_t* x, const int64_t* r, const 
 }
 
 int rzk_open_response_batch(rzk_ctx* c, const int64_t* y, const int64_t* r, const int64_t* d, int64_t* z, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !y || !r || !d || !z) return RZK_E_ARG;
   std::vector<HostBuf> bufs = {IN(y, polys(c, B * c->k)), IN(r, polys(c, B * c->k)), IN(d, polys(c, B)),
                                OUT(z, polys(c, B * c->k))};
@@ -1550,6 +1586,7 @@ int rzk_open_response_batch(rzk_ctx* c, const int64_t* y, const int64_t* r, cons
 
 int rzk_open_verify_batch(rzk_ctx* c, const int64_t* z, const int64_t* t, const int64_t* cm, const int64_t* d,
                           uint8_t* accept, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !z || !t || !cm || !d || !accept) return RZK_E_ARG;
   std::vector<HostBuf> bufs = {IN(z, polys(c, B * c->k)), IN(t, polys(c, B * c->n)),
                                IN(cm, polys(c, B * (c->n + c->l))), IN(d, polys(c, B)), OUT(accept, B)};
@@ -1560,6 +1597,7 @@ int rzk_open_verify_batch(rzk_ctx* c, const int64_t* z, const int64_t* t, const 
 int rzk_linear_commit_batch(rzk_ctx* c, const int64_t* g, const int64_t* x, const int64_t* r, const int64_t* rp,
                             const int64_t* y, const int64_t* yp, int64_t* cm, int64_t* cpm, int64_t* t, int64_t* tp,
                             int64_t* u, uint8_t* ok, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !g || !x || !r || !rp || !y || !yp || !cm || !cpm || !t || !tp || !u) return RZK_E_ARG;
   const size_t k = c->k, n = c->n, l = c->l;
   std::vector<HostBuf> bufs = {IN(g, polys(c, B)),          IN(x, polys(c, B * l)),        IN(r, polys(c, B * k)),
@@ -1574,6 +1612,7 @@ int rzk_linear_commit_batch(rzk_ctx* c, const int64_t* g, const int64_t* x, cons
 
 int rzk_linear_response_batch(rzk_ctx* c, const int64_t* y, const int64_t* yp, const int64_t* r, const int64_t* rp,
                               const int64_t* d, int64_t* z, int64_t* zp, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !y || !yp || !r || !rp || !d || !z || !zp) return RZK_E_ARG;
   const size_t kb = polys(c, B * c->k);
   std::vector<HostBuf> bufs = {IN(y, kb), IN(yp, kb), IN(r, kb), IN(rp, kb), IN(d, polys(c, B)), OUT(z, kb), OUT(zp, kb)};
@@ -1585,6 +1624,7 @@ int rzk_linear_response_batch(rzk_ctx* c, const int64_t* y, const int64_t* yp, c
 int rzk_linear_verify_batch(rzk_ctx* c, const int64_t* z, const int64_t* zp, const int64_t* cm, const int64_t* cpm,
                             const int64_t* g, const int64_t* t, const int64_t* tp, const int64_t* u, const int64_t* d,
                             uint8_t* accept, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !z || !zp || !cm || !cpm || !g || !t || !tp || !u || !d || !accept) return RZK_E_ARG;
   const size_t k = c->k, n = c->n, l = c->l;
   std::vector<HostBuf> bufs = {IN(z, polys(c, B * k)),   IN(zp, polys(c, B * k)), IN(cm, polys(c, B * (n + l))),
@@ -1600,6 +1640,7 @@ int rzk_linear_verify_batch(rzk_ctx* c, const int64_t* z, const int64_t* zp, con
 int rzk_sum_commit_batch(rzk_ctx* c, uint32_t V, const int64_t* gs, const int64_t* xs, const int64_t* rs,
                          const int64_t* rp, const int64_t* ys, const int64_t* yp, int64_t* cs, int64_t* cpm,
                          int64_t* ts, int64_t* tp, int64_t* u, uint8_t* ok, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || V == 0 || !gs || !xs || !rs || !rp || !ys || !yp || !cs || !cpm || !ts || !tp || !u) return RZK_E_ARG;
   const size_t k = c->k, n = c->n, l = c->l;
   std::vector<HostBuf> bufs = {IN(gs, polys(c, B * V)),        IN(xs, polys(c, B * V * l)), IN(rs, polys(c, B * V * k)),
@@ -1615,6 +1656,7 @@ int rzk_sum_commit_batch(rzk_ctx* c, uint32_t V, const int64_t* gs, const int64_
 
 int rzk_sum_response_batch(rzk_ctx* c, uint32_t V, const int64_t* ys, const int64_t* yp, const int64_t* rs,
                            const int64_t* rp, const int64_t* d, int64_t* zs, int64_t* zp, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || V == 0 || !ys || !yp || !rs || !rp || !d || !zs || !zp) return RZK_E_ARG;
   const size_t k = c->k;
   std::vector<HostBuf> bufs = {IN(ys, polys(c, B * V * k)), IN(yp, polys(c, B * k)), IN(rs, polys(c, B * V * k)),
@@ -1628,6 +1670,7 @@ int rzk_sum_response_batch(rzk_ctx* c, uint32_t V, const int64_t* ys, const int6
 int rzk_sum_verify_batch(rzk_ctx* c, uint32_t V, const int64_t* zs, const int64_t* zp, const int64_t* cs,
                          const int64_t* cpm, const int64_t* gs, const int64_t* ts, const int64_t* tp, const int64_t* u,
                          const int64_t* d, uint8_t* accept, size_t B) {
+  if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || V == 0 || !zs || !zp || !cs || !cpm || !gs || !ts || !tp || !u || !d || !accept) return RZK_E_ARG;
   const size_t k = c->k, n = c->n, l = c->l;
   std::vector<HostBuf> bufs = {IN(zs, polys(c, B * V * k)),       IN(zp, polys(c, B * k)),

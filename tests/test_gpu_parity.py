@@ -107,6 +107,18 @@ def test_empty_batch(torch_mod):
     e = np.empty((0, 512), dtype=np.int64)
     assert ctx.polymul(e, e).shape == (0, 512)
     assert ctx.add(e, e).shape == (0, 512)
+    # phase-level and commitment entry points with no proofs: nothing launched, empty results
+    rng = np.random.default_rng(0)
+    ctx.load_key(synth.key(rng, 512, 1, 3, 1))
+    x0 = np.empty((0, 1, 512), dtype=np.int64)
+    v0 = np.empty((0, 3, 512), dtype=np.int64)
+    c0, t0, ok0 = ctx.open_commit(x0, v0, v0)
+    assert c0.shape == (0, 2, 512) and t0.shape == (0, 1, 512) and ok0.shape == (0,)
+    assert ctx.open_response(v0, v0, e).shape == (0, 3, 512)
+    assert ctx.open_verify(v0, t0, c0, e).shape == (0,)
+    cm0, okc0 = ctx.commit(x0, v0)
+    assert cm0.shape == (0, 2, 512) and ctx.commitment_verify(cm0, x0, v0).shape == (0,)
+    assert ctx.sample_challenge(1, 0, (0,)).shape == (0, 512)
 
 
 # ---- Mat seam ------------------------------------------------------------------------------------------------------

@@ -47,7 +47,8 @@ typedef struct rzk_ctx rzk_ctx;
 
 /* ---- context ---------------------------------------------------------------------------------- */
 /* Mirrors Params<ZqI64<Q>> (src/params.rs:18-36) + const generics N and Q.
- * q: ring modulus Q (odd, < 2^32; default 3515337053, src/params.rs:121), NOT Params.q.
+ * q: ring modulus Q, NOT Params.q: odd, 1073692673 < q <= 4294606851 (above the first auxiliary NTT prime,
+ *    (q-1)/2 below twice the third; the default 3515337053, src/params.rs:121, lies inside), else RZK_E_UNSUPPORTED.
  * N: power of two in [4, 2048].  512 / 1024 / 2048 run the NTT kernels (the BASELINE sizes); 4 .. 256
  * (the sizes of the reference's own tests: src/mat.rs:241 N=4, tests/test.rs:8 N=16) run a schoolbook
  * kernel, same results, for drop-in completeness.  Requires k > n >= 1, l >= 1, n + l <= k

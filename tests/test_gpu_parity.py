@@ -647,3 +647,56 @@ def test_device_buffers_at_8_byte_alignment(torch_mod):
         assert np.array_equal(c[b].cpu().numpy(), c_ref) and np.array_equal(t[b].cpu().numpy(), t_ref)
         assert np.array_equal(z[b].cpu().numpy(), O.open_response(P, y[b], r[b], d[b]))
     assert acc.cpu().numpy().tolist() == [1] * B
+
+
+# ---- other parameter sets: the reference is generic in Q, kappa and b (src/params.rs:18-36) -------------------------
+@pytest.mark.parametrize("q", [1073741827, 4294606851])
+@pytest.mark.parametrize("N", [512, 1024])
+def test_other_moduli_and_parameters(torch_mod, N, q):
+    """Smallest and largest supported ring moduli (just above 2^30; just below 4 p2, include/rzk.h) with kappa = 60
+    (the reference's own challenge-set test, challenge_space.rs:60) and b = 3: every mod-q path of the kernels
+    (32-bit add/sub with wrap-around, 64-bit reductions of the rotation sums, CRT constants) against the oracle."""
+    from ring_zk_amd import Context
+
+    n, k, l, kappa, b = 1, 3, 1, 60, 3
+    ctx = Context(N, n, k, l, kappa=kappa, b=b, q=q)
+    P = O.Params(N, n, k, l, kappa, b, q)
+    assert (ctx.sigma, ctx.commit_bound, ctx.verify_bound) == (P.sigma, P.commit_bound, P.verify_bound)
+    half = (q - 1) // 2
+    rng = np.random.default_rng(q % 1000 + N)
+    A = O.key_build(P, rng.integers(-half, half + 1, (n, k - n, N)), rng.integers(-half, half + 1, (l, k - n - l, N)))
+    ctx.load_key(A)
+    B = 4
+    x = rng.integers(-half, half + 1, (B, l, N))
+    r = rng.integers(-b, b + 1, (B, k, N))
+    y = np.trunc(rng.normal(0, P.sigma, (B, k, N))).astype(np.int64)
+    d = np.zeros((B, N), dtype=np.int64)
+    for i in range(B):
+        pos = rng.choice(N, kappa, replace=False)
+        d[i, pos] = rng.choice([-1, 1], kappa)
+    x[0, 0, :4] = [half, -half, half, -half]              # extreme coefficients
+    c, t, ok = ctx.open_commit(x, r, y)
+    z = ctx.open_response(y, r, d)
+    zt = z.copy()
+    zt[3, 1, 7] = O.center(int(zt[3, 1, 7]) + 1, q)
+    acc = ctx.open_verify(zt, t, c, d)
+    for i in range(B):
+        c_ref, t_ref, ok_ref = O.open_commit(P, A, x[i], r[i], y[i])
+        assert np.array_equal(c[i], c_ref) and np.array_equal(t[i], t_ref) and bool(ok[i]) == ok_ref
+        assert np.array_equal(z[i], O.open_response(P, y[i], r[i], d[i]))
+        assert int(acc[i]) == int(O.open_verify(P, A, zt[i], t[i], c[i], d[i]) == 1)
+    assert acc.tolist() == [1, 1, 1, 0]
+    # full-range products (three primes) and a full-range "challenge" (16-bit passes of the rotation kernel)
+    a = rng.integers(-half, half + 1, (B, N))
+    bb = rng.integers(-half, half + 1, (B, N))
+    prod = ctx.polymul(a, bb)
+    for i in range(B):
+        assert np.array_equal(prod[i], O.poly_mul(a[i], bb[i], q))
+    zz = ctx.open_response(y, x.repeat(k, axis=1), a)      # r := full-range, d := full-range
+    for i in range(B):
+        assert np.array_equal(zz[i], O.open_response(P, y[i], x.repeat(k, axis=1)[i], a[i]))
+    # device-side samplers respect the modulus of the context
+    u = ctx.sample_uniform(1, 0, half, (8,)).cpu().numpy()
+    assert u.min() >= -half and u.max() <= half and np.abs(u).max() > 0.9 * half
+    dd = ctx.sample_challenge(1, 1, (8,)).cpu().numpy()
+    assert (np.abs(dd).sum(axis=1) == kappa).all()

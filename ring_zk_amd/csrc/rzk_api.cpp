@@ -807,7 +807,9 @@ bool can_fuse(rzk_ctx* c, int id, uint32_t var, uint64_t bound) {
 
 int run_norm(rzk_ctx* c, const int64_t* v, uint32_t rows, uint64_t bound, uint8_t* ok, uint64_t B, int mode,
              int shift) {
-  if (bound >= (1ull << 32)) return fail(c, RZK_E_ARG, "norm bound must be below 2^32");
+  // canonical coefficients are below 2^31 in magnitude, so sum c^2 < 2^73: every bound from 2^37 on holds for
+  // all inputs; clamping there keeps (bound+1)^2 inside 128 bits for any u64 bound (sigma grows with b)
+  if (bound > (1ull << 40)) bound = 1ull << 40;
   uint64_t hi, lo;
   norm_limit(bound, hi, lo);
   if (c->small) return check_launch(c, launch_norm_small(c->N, cfg_of(c), v, rows, hi, lo, ok, B, mode, shift), "norm kernel");

@@ -700,3 +700,32 @@ def test_other_moduli_and_parameters(torch_mod, N, q):
     assert u.min() >= -half and u.max() <= half and np.abs(u).max() > 0.9 * half
     dd = ctx.sample_challenge(1, 1, (8,)).cpu().numpy()
     assert (np.abs(dd).sum(axis=1) == kappa).all()
+
+
+def test_norm_bounds_beyond_32_bits(torch_mod):
+    """b = 2^22 makes sigma = 11*kappa*b*floor(sqrt(kN)) and both norm bounds exceed 2^32 (params.rs:94-118 computes
+    them in usize); every canonical polynomial then satisfies them and the predicates must say so."""
+    from ring_zk_amd import Context
+
+    N, n, k, l, kappa, b = 512, 1, 3, 1, 36, 1 << 22
+    ctx = Context(N, n, k, l, kappa=kappa, b=b)
+    P = O.Params(N, n, k, l, kappa, b)
+    assert ctx.commit_bound == P.commit_bound > 1 << 32 and ctx.verify_bound == P.verify_bound > 1 << 32
+    rng = np.random.default_rng(8)
+    A = synth.key(rng, N, n, k, l)
+    ctx.load_key(A)
+    B = 3
+    x = synth.uniform(rng, (B, l, N))
+    r = rng.integers(-b, b + 1, (B, k, N))
+    y = synth.uniform(rng, (B, k, N))                      # (i64) N(0, sigma) reduced mod q: spread over the whole range
+    d = synth.challenge(rng, (B,), N, kappa)
+    c, t, ok = ctx.open_commit(x, r, y)
+    z = ctx.open_response(y, r, d)
+    acc = ctx.open_verify(z, t, c, d)
+    for i in range(B):
+        c_ref, t_ref, ok_ref = O.open_commit(P, A, x[i], r[i], y[i])
+        assert np.array_equal(c[i], c_ref) and np.array_equal(t[i], t_ref) and bool(ok[i]) == ok_ref == True
+        assert np.array_equal(z[i], O.open_response(P, y[i], r[i], d[i]))
+        assert int(acc[i]) == int(O.open_verify(P, A, z[i], t[i], c[i], d[i]) == 1) == 1
+    assert ctx.norm2_le(y, P.verify_bound).tolist() == [1] * B
+    assert ctx.norm2_le(y, 5).tolist() == [0] * B

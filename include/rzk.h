@@ -96,6 +96,11 @@ int rzk_matvec_batch_dev(rzk_ctx* ctx, int which, const int64_t* v, const int64_
 int rzk_cmul_batch(rzk_ctx* ctx, const int64_t* m, uint32_t rows, const int64_t* p, int64_t* out, size_t B);
 int rzk_cmul_batch_dev(rzk_ctx* ctx, const int64_t* m, uint32_t rows, const int64_t* p, int64_t* out,
                        size_t B);
+/* Any int64 coefficient -> the centred representative in [-(q-1)/2, (q-1)/2] (what ZqI64::from does).  Every
+ * other entry point REQUIRES canonical inputs (it reads only the low word of a coefficient); data that did not
+ * pass through a ZqI64 goes through this first.  in, out: [count][N], may alias. */
+int rzk_canonicalize_batch(rzk_ctx* ctx, const int64_t* in, int64_t* out, size_t count);
+int rzk_canonicalize_batch_dev(rzk_ctx* ctx, const int64_t* in, int64_t* out, size_t count);
 /* Mat::add / Mat::sub (src/mat.rs:122-140, 147-165) on `count` polynomials */
 int rzk_add_batch(rzk_ctx* ctx, const int64_t* a, const int64_t* b, int64_t* out, size_t count);
 int rzk_add_batch_dev(rzk_ctx* ctx, const int64_t* a, const int64_t* b, int64_t* out, size_t count);

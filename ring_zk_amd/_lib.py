@@ -37,6 +37,7 @@ SIGNATURES = {
     "rzk_polymul_batch": (C.c_int, [_CTX, _I64, _I64, _I64, _SZ]),
     "rzk_matvec_batch": (C.c_int, [_CTX, C.c_int, _I64, _I64, _I64, _SZ]),
     "rzk_cmul_batch": (C.c_int, [_CTX, _I64, C.c_uint32, _I64, _I64, _SZ]),
+    "rzk_canonicalize_batch": (C.c_int, [_CTX, _I64, _I64, _SZ]),
     "rzk_add_batch": (C.c_int, [_CTX, _I64, _I64, _I64, _SZ]),
     "rzk_sub_batch": (C.c_int, [_CTX, _I64, _I64, _I64, _SZ]),
     "rzk_norm2_le_batch": (C.c_int, [_CTX, _I64, C.c_uint32, C.c_uint64, _U8, _SZ]),

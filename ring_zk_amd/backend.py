@@ -188,6 +188,14 @@ class Context:
     def sub(self, a, b):
         return self._addsub("rzk_sub_batch", a, b)
 
+    def canonicalize(self, a):
+        """Any int64 coefficients -> centred residues mod q (the other calls require canonical inputs)."""
+        cnt = self._shape(a, self.N)
+        out = self._empty(a, tuple(a.shape))
+        dev, p = self._prep([a, out], [np.int64] * 2)
+        self._check(self._fn("rzk_canonicalize_batch", dev)(self._h, p[0], p[1], cnt))
+        return out
+
     def norm2_le(self, v, bound: int):
         rows = int(v.shape[-2])
         B = self._shape(v, rows, self.N)

@@ -1134,6 +1134,12 @@ int rzk_cmul_batch_dev(rzk_ctx* c, const int64_t* m, uint32_t rows, const int64_
   return run_program(c, PG_CMUL, rows, {{m, rows, 0}, {p, 1, 0}, {out, rows, 0}}, nullptr, 1, B);
 }
 
+int rzk_canonicalize_batch_dev(rzk_ctx* c, const int64_t* in, int64_t* out, size_t count) {
+  if (c && count == 0) return RZK_OK;
+  if (!c || !in || !out) return RZK_E_ARG;
+  return check_launch(c, launch_canonicalize(cfg_of(c), in, out, (uint64_t)count * c->N, c->q), "canonicalize kernel");
+}
+
 int rzk_add_batch_dev(rzk_ctx* c, const int64_t* a, const int64_t* b, int64_t* out, size_t count) {
   if (c && count == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !a || !b || !out) return RZK_E_ARG;
@@ -1502,6 +1508,13 @@ int rzk_cmul_batch(rzk_ctx* c, const int64_t* m, uint32_t rows, const int64_t* p
   if (!c || !m || !p || !out || rows == 0) return RZK_E_ARG;
   std::vector<HostBuf> bufs = {IN(m, polys(c, B * rows)), IN(p, polys(c, B)), OUT(out, polys(c, B * rows))};
   HOST_WRAP(rzk_cmul_batch_dev(c, DEV(0, const int64_t*), rows, DEV(1, const int64_t*), DEV(2, int64_t*), B));
+}
+
+int rzk_canonicalize_batch(rzk_ctx* c, const int64_t* in, int64_t* out, size_t count) {
+  if (c && count == 0) return RZK_OK;
+  if (!c || !in || !out) return RZK_E_ARG;
+  std::vector<HostBuf> bufs = {IN(in, polys(c, count)), OUT(out, polys(c, count))};
+  HOST_WRAP(rzk_canonicalize_batch_dev(c, DEV(0, const int64_t*), DEV(1, int64_t*), count));
 }
 
 int rzk_add_batch(rzk_ctx* c, const int64_t* a, const int64_t* b, int64_t* out, size_t count) {

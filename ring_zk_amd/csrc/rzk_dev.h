@@ -167,6 +167,7 @@ int launch_sample_gauss(const LaunchCfg& cfg, int64_t* out, uint64_t npoly, uint
                         uint32_t stream, double sigma);
 int launch_sample_challenge(const LaunchCfg& cfg, int64_t* out, uint64_t npoly, uint32_t n_ring, uint64_t seed,
                             uint32_t stream, uint32_t kappa);
+int launch_canonicalize(const LaunchCfg& cfg, const int64_t* in, int64_t* out, uint64_t ncoef, int64_t q);
 int launch_addsub(const LaunchCfg& cfg, bool sub, const int64_t* a, const int64_t* b, int64_t* out,
                   uint64_t ncoef, const DevTables* d_T);
 // ok[b] = (all `rows` polys of proof b have sum c^2 < limit), limit = (bound+1)^2 given as hi:lo.

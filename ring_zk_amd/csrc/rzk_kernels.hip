@@ -1752,6 +1752,28 @@ int launch_sample_challenge(const LaunchCfg& cfg, int64_t* out, uint64_t npoly, 
   return 0;
 }
 
+// any int64 -> centred representative mod q (utility for data that does not come from a ZqI64: the hot kernels
+// assume canonical inputs and read only the low word of every coefficient)
+__global__ void __launch_bounds__(256) canonicalize_kernel(const int64_t* __restrict__ in, int64_t* __restrict__ out,
+                                                          uint64_t ncoef, int64_t q) {
+  const int64_t half = (q - 1) / 2;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < ncoef; i += (uint64_t)gridDim.x * 256) {
+    int64_t r = in[i] % q;          // sign of the dividend, |r| < q
+    if (r > half) r -= q;
+    if (r < -half) r += q;
+    out[i] = r;
+  }
+}
+int launch_canonicalize(const LaunchCfg& cfg, const int64_t* in, int64_t* out, uint64_t ncoef, int64_t q) {
+  if (ncoef == 0) return 0;
+  uint64_t blocks = (ncoef + 255) / 256;
+  const uint64_t cap = (uint64_t)cfg.num_cus * 32;
+  if (blocks > cap) blocks = cap;
+  hipLaunchKernelGGL(canonicalize_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)cfg.stream, in, out, ncoef, q);
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+
 int launch_addsub(const LaunchCfg& cfg, bool sub, const int64_t* a, const int64_t* b, int64_t* out,
                   uint64_t ncoef, const DevTables* T) {
   if (ncoef == 0) return 0;

@@ -729,3 +729,15 @@ def test_norm_bounds_beyond_32_bits(torch_mod):
         assert int(acc[i]) == int(O.open_verify(P, A, z[i], t[i], c[i], d[i]) == 1) == 1
     assert ctx.norm2_le(y, P.verify_bound).tolist() == [1] * B
     assert ctx.norm2_le(y, 5).tolist() == [0] * B
+
+
+def test_canonicalize(torch_mod):
+    ctx = ctx_for(512)
+    rng = np.random.default_rng(3)
+    a = rng.integers(-2 ** 62, 2 ** 62, (5, 512), dtype=np.int64)
+    a[0, :6] = [0, HALF, HALF + 1, -HALF, -HALF - 1, Q]
+    a[1, :3] = [np.iinfo(np.int64).max, np.iinfo(np.int64).min, -Q]
+    want = np.array([[O.center(int(v)) for v in row] for row in a], dtype=np.int64)
+    assert np.array_equal(ctx.canonicalize(a), want)
+    assert np.array_equal(ctx.canonicalize(dev(torch_mod, a)).cpu().numpy(), want)
+    assert np.array_equal(ctx.canonicalize(want), want)      # idempotent

@@ -46,6 +46,32 @@ struct Params {
   }
   // params.rs:94-98
   uint64_t standard_deviation(size_t deg_n) const { return b * (11 * kappa) * isqrt(k * deg_n); }
+
+  // ZqI64::from: the centred representative mod the ring modulus
+  int64_t center(int64_t v) const {
+    int64_t r = v % modulus;
+    const int64_t half = (modulus - 1) / 2;
+    if (r > half) r -= modulus;
+    if (r < -half) r += modulus;
+    return r;
+  }
+  // prepare_scalar (params.rs:89-91): integers -> one polynomial (coefficients reduced into Z_q)
+  template <size_t N>
+  Poly prepare_scalar(const std::vector<int64_t>& scalar) const {
+    static_assert(N != 0 && (N & (N - 1)) == 0, "N must be a power of two (params.rs:86-87)");
+    if (scalar.size() > N) throw std::runtime_error("prepare_scalar: more than N coefficients");
+    Poly p;
+    for (int64_t v : scalar) p.push_back(center(v));
+    return p;
+  }
+  // prepare_value (params.rs:67-78): l integer vectors -> the message polynomials; panics unless value.len() == l
+  template <size_t N>
+  PolyVec prepare_value(const std::vector<std::vector<int64_t>>& value) const {
+    if (value.size() != l) throw std::runtime_error("prepare_value: value.len() != l (params.rs:71)");
+    PolyVec out;
+    for (const auto& v : value) out.push_back(prepare_scalar<N>(v));
+    return out;
+  }
 };
 
 inline void flatten(const PolyVec& v, size_t N, std::vector<int64_t>& out) {

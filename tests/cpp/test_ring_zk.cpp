@@ -152,8 +152,29 @@ static void test_panics() {
   std::printf("test_panics ok\n");
 }
 
+// src/params.rs:145-168: standard_deviation KAT, prepare_scalar / prepare_value
+static void test_params() {
+  Params params;
+  REQUIRE(params.standard_deviation(1024) == 21780);   // params.rs:149
+  const Poly p = params.prepare_scalar<4>({1, 2, 3, 4});
+  REQUIRE(p.size() == 4 && p[3] == 4);                   // deg() == 3 (params.rs:157)
+  const PolyVec v = params.prepare_value<4>({{1, 2, 3, 4}});
+  REQUIRE(v.size() == 1 && v[0].size() == 4);            // params.rs:165-166
+  REQUIRE(params.prepare_scalar<4>({params.modulus + 5})[0] == 5);       // Into<ZqI64>: reduced mod Q
+  REQUIRE(params.prepare_scalar<4>({(params.modulus - 1) / 2 + 1})[0] == -(params.modulus - 1) / 2);
+  bool threw = false;
+  try {
+    (void)params.prepare_value<4>({{1}, {2}});           // value.len() != l panics (params.rs:71)
+  } catch (const std::runtime_error&) {
+    threw = true;
+  }
+  REQUIRE(threw);
+  std::printf("test_params ok\n");
+}
+
 int main(int argc, char** argv) {
   const int iters = argc > 1 ? std::atoi(argv[1]) : 100;   // tests/test.rs: 100 iterations each
+  test_params();
   test_open_proof(iters);
   test_linear_proof(iters);
   test_sum_proof(iters);

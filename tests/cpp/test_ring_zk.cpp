@@ -33,13 +33,33 @@ static Poly random_value(Rng& rng, int64_t bound) {
   return p;
 }
 
+// Params::default() (tests/test.rs), or the shape given in TEST_SHAPE = "n,k,l" (larger shapes drive the
+// row-group / row-block / shared-operand kernels through the same reference-style flows)
+static Params shape_params() {
+  Params p;
+  if (const char* e = std::getenv("TEST_SHAPE")) {
+    unsigned n = 0, k = 0, l = 0;
+    if (std::sscanf(e, "%u,%u,%u", &n, &k, &l) == 3) {
+      p.n = n;
+      p.k = k;
+      p.l = l;
+    }
+  }
+  return p;
+}
+static PolyVec random_message(Rng& rng, const Params& p) {
+  PolyVec x;
+  for (size_t i = 0; i < p.l; ++i) x.push_back(random_value(rng, p.q));
+  return x;
+}
+
 static void test_open_proof(int iters) {
   Rng rng(1);
-  Params params;
+  Params params = shape_params();
   auto be = std::make_shared<Backend<N>>(params);
   for (int it = 0; it < iters; ++it) {
     CommitmentKey<N> ck(rng, be);
-    PolyVec x = {random_value(rng, params.q)};
+    PolyVec x = random_message(rng, params);
     OpenProofProver<N> prover(ck);
     OpenProofVerifier<N> verifier(ck);
     auto [rctx, cm] = prover.commit(rng, x);
@@ -68,11 +88,11 @@ static void test_open_proof(int iters) {
 
 static void test_linear_proof(int iters) {
   Rng rng(2);
-  Params params;
+  Params params = shape_params();
   auto be = std::make_shared<Backend<N>>(params);
   for (int it = 0; it < iters; ++it) {
     CommitmentKey<N> ck(rng, be);
-    PolyVec x = {random_value(rng, params.q)};
+    PolyVec x = random_message(rng, params);
     Poly g = random_value(rng, params.q);
     g.resize(N, 0);
     LinearProofProver<N> prover(ck);
@@ -94,14 +114,14 @@ static void test_linear_proof(int iters) {
 
 static void test_sum_proof(int iters) {
   Rng rng(3);
-  Params params;
+  Params params = shape_params();
   constexpr size_t VL = 4;   // tests/test.rs:65
   auto be = std::make_shared<Backend<N>>(params);
   for (int it = 0; it < iters; ++it) {
     CommitmentKey<N> ck(rng, be);
     std::vector<PolyVec> xs;
     PolyVec gs;
-    for (size_t i = 0; i < VL; ++i) xs.push_back({random_value(rng, params.q)});
+    for (size_t i = 0; i < VL; ++i) xs.push_back(random_message(rng, params));
     for (size_t i = 0; i < VL; ++i) {
       Poly g = random_value(rng, params.q);
       g.resize(N, 0);

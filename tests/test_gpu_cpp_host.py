@@ -9,8 +9,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("ring_n", [16, 512])   # 16 is the reference's own test size (tests/test.rs:8)
-def test_cpp_host_mirror_runs_reference_style_tests(tmp_path, ring_n):
+# 16 is the reference's own test size (tests/test.rs:8); the larger shapes drive the row-group, shared-operand and
+# row-block kernels through the same flows
+@pytest.mark.parametrize("ring_n,shape,iters", [(16, "", 100), (512, "", 100), (512, "2,5,2", 10), (2048, "2,5,2", 2)])
+def test_cpp_host_mirror_runs_reference_style_tests(tmp_path, ring_n, shape, iters):
     from ring_zk_amd import build
 
     so = build.build_library()
@@ -19,6 +21,9 @@ def test_cpp_host_mirror_runs_reference_style_tests(tmp_path, ring_n):
     subprocess.check_call(["g++", "-O2", "-std=c++17", f"-DTEST_N={ring_n}",
                            os.path.join(ROOT, "tests", "cpp", "test_ring_zk.cpp"),
                            "-L" + libdir, "-lrzk_hip", "-Wl,-rpath," + libdir, "-o", exe])
-    out = subprocess.run([exe, "100"], capture_output=True, text=True, timeout=600)
+    env = dict(os.environ)
+    if shape:
+        env["TEST_SHAPE"] = shape
+    out = subprocess.run([exe, str(iters)], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all ok" in out.stdout

@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """Experiment: run the OpenProof cycle of one 4096-proof batch as S independent sub-batches on S HIP streams,
 so that the HBM-bound response rows of one sub-batch overlap the VALU-bound commit / verify rows of another."""
+import os
 import sys
 import time
 
-import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
 
-from ring_zk_amd import Context, synth
+from ring_zk_amd import Context, synth  # noqa: E402
 
 N, n, k, l, B = 1024, 1, 3, 1, 4096
 dev = torch.device("cuda", 0)

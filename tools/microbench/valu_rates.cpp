@@ -257,12 +257,14 @@ struct Test {
   double ops_per_iter;  // wave-instructions (or butterflies) per thread per ITER step
 };
 
-int main() {
+int main(int argc, char** argv) {
   hipDeviceProp_t prop;
   CK(hipGetDeviceProperties(&prop, 0));
   int cus = prop.multiProcessorCount;
   printf("device %s CUs=%d clock=%d kHz\n", prop.name, cus, prop.clockRate);
-  const int blocks = cus * 8, threads = 256;
+  // waves per SIMD = blocks per CU (256-thread blocks): default 8, argv[1] overrides (e.g. 4 = the row kernel's occupancy)
+  const int per_cu = argc > 1 ? std::atoi(argv[1]) : 8;
+  const int blocks = cus * per_cu, threads = 256;
   uint32_t* out;
   CK(hipMalloc(&out, sizeof(uint32_t) * blocks * threads));
   std::vector<Test> tests = {

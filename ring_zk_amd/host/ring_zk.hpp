@@ -116,6 +116,116 @@ class Backend {
   rzk_ctx* ctx_ = nullptr;
 };
 
+// ---- Mat (src/mat.rs:11-238): m x n matrix of polynomials; arithmetic goes through the C ABI ------------------
+template <size_t N>
+class Mat {
+ public:
+  std::vector<PolyVec> polynomials;   // rows of polynomials (trimmed or dense), as in mat.rs:16
+
+  Mat() = default;
+  explicit Mat(std::vector<PolyVec> rows) : polynomials(std::move(rows)) {}
+  static Mat from_element(size_t m, size_t n, const Poly& element) {            // mat.rs:24-31
+    return Mat(std::vector<PolyVec>(m, PolyVec(n, element)));
+  }
+  static Mat diag(size_t m, size_t n, const Poly& element) {                    // mat.rs:33-44
+    Mat out(std::vector<PolyVec>(m, PolyVec(n, Poly{})));
+    for (size_t i = 0; i < m && i < n; ++i) out.polynomials[i][i] = element;
+    return out;
+  }
+  static Mat from_vec(const PolyVec& v) {                                       // mat.rs:46-50
+    Mat out;
+    for (const Poly& p : v) out.polynomials.push_back(PolyVec{p});
+    return out;
+  }
+  PolyVec one_d_mat_to_vec() const {                                            // mat.rs:56-64
+    PolyVec v;
+    for (const PolyVec& row : polynomials) {
+      if (row.size() != 1) throw std::runtime_error("Matrix dimension is not (m x 1)");
+      v.push_back(row[0]);
+    }
+    return v;
+  }
+  std::pair<size_t, size_t> dim() const {                                       // mat.rs:79-87
+    return {polynomials.size(), polynomials.empty() ? 0 : polynomials[0].size()};
+  }
+  // dot (mat.rs:95-115): (m x n) . (n x p); every entry is sum_k a_ik * b_kj, evaluated as n batched products
+  Mat dot(const Mat& other, const Backend<N>& be) const {
+    const auto [m, n] = dim();
+    const auto [n2, p] = other.dim();
+    if (n != n2) throw std::runtime_error("Mat::dot: dimension mismatch (mat.rs:103)");
+    Mat out(std::vector<PolyVec>(m, PolyVec(p, Poly(N, 0))));
+    std::vector<int64_t> lhs, rhs, prod(m * p * N), acc(m * p * N, 0);
+    for (size_t kk = 0; kk < n; ++kk) {
+      lhs.clear();
+      rhs.clear();
+      for (size_t i = 0; i < m; ++i)
+        for (size_t j = 0; j < p; ++j) {
+          flatten(PolyVec{polynomials[i][kk]}, N, lhs);
+          flatten(PolyVec{other.polynomials[kk][j]}, N, rhs);
+        }
+      be.check(rzk_polymul_batch(be.ctx(), lhs.data(), rhs.data(), prod.data(), m * p));
+      be.check(rzk_add_batch(be.ctx(), acc.data(), prod.data(), acc.data(), m * p));
+    }
+    const PolyVec flat = unflatten(acc, N);
+    for (size_t i = 0; i < m; ++i)
+      for (size_t j = 0; j < p; ++j) out.polynomials[i][j] = flat[i * p + j];
+    return out;
+  }
+  Mat add(const Mat& other, const Backend<N>& be) const { return addsub(other, be, false); }   // mat.rs:122-140
+  Mat sub(const Mat& other, const Backend<N>& be) const { return addsub(other, be, true); }    // mat.rs:147-165
+  Mat componentwise_mul(const Poly& element, const Backend<N>& be) const {      // mat.rs:168-178
+    const auto [m, n] = dim();
+    std::vector<int64_t> a, e, out(m * n * N);
+    for (const PolyVec& row : polynomials) flatten(row, N, a);
+    flatten(PolyVec{element}, N, e);
+    if (m * n) be.check(rzk_cmul_batch(be.ctx(), a.data(), (uint32_t)(m * n), e.data(), out.data(), 1));
+    return reshape(out, m, n);
+  }
+  void extend_rows(const Mat& other) {                                          // mat.rs:186-196
+    if (dim().second != other.dim().second) throw std::runtime_error("Mat::extend_rows: column counts differ");
+    polynomials.insert(polynomials.end(), other.polynomials.begin(), other.polynomials.end());
+  }
+  std::pair<Mat, Mat> split_rows(size_t r) const {                              // mat.rs:203-213: (m - r) x n and r x n
+    const size_t m = dim().first;
+    if (r > m) throw std::runtime_error("Mat::split_rows: r > rows");
+    return {Mat(std::vector<PolyVec>(polynomials.begin(), polynomials.begin() + (m - r))),
+            Mat(std::vector<PolyVec>(polynomials.begin() + (m - r), polynomials.end()))};
+  }
+  void extend_cols(const Mat& other) {                                          // mat.rs:221-233
+    if (dim().first != other.dim().first) throw std::runtime_error("Mat::extend_cols: row counts differ");
+    for (size_t i = 0; i < polynomials.size(); ++i)
+      polynomials[i].insert(polynomials[i].end(), other.polynomials[i].begin(), other.polynomials[i].end());
+  }
+  // derived PartialEq (mat.rs:11) on canonical forms: trailing zeros do not matter
+  bool operator==(const Mat& o) const {
+    if (dim() != o.dim()) return false;
+    for (size_t i = 0; i < polynomials.size(); ++i)
+      for (size_t j = 0; j < polynomials[i].size(); ++j)
+        if (dense(polynomials[i][j], N) != dense(o.polynomials[i][j], N)) return false;
+    return true;
+  }
+
+ private:
+  static Mat reshape(const std::vector<int64_t>& flat, size_t m, size_t n) {
+    const PolyVec v = unflatten(flat, N);
+    Mat out(std::vector<PolyVec>(m, PolyVec(n)));
+    for (size_t i = 0; i < m; ++i)
+      for (size_t j = 0; j < n; ++j) out.polynomials[i][j] = v[i * n + j];
+    return out;
+  }
+  Mat addsub(const Mat& other, const Backend<N>& be, bool subtract) const {
+    if (dim() != other.dim()) throw std::runtime_error("Mat::add/sub: dimension mismatch (mat.rs:129-130, 154-155)");
+    const auto [m, n] = dim();
+    std::vector<int64_t> a, b, out(m * n * N);
+    for (const PolyVec& row : polynomials) flatten(row, N, a);
+    for (const PolyVec& row : other.polynomials) flatten(row, N, b);
+    if (m * n)
+      be.check(subtract ? rzk_sub_batch(be.ctx(), a.data(), b.data(), out.data(), m * n)
+                        : rzk_add_batch(be.ctx(), a.data(), b.data(), out.data(), m * n));
+    return reshape(out, m, n);
+  }
+};
+
 // ---- samplers (host side, as in the reference) -------------------------------------------------------------
 template <size_t N>
 Poly random_polynomial_within(Rng& rng, int64_t bound) {   // polynomial.rs:14-25

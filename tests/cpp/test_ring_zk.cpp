@@ -172,6 +172,45 @@ static void test_panics() {
   std::printf("test_panics ok\n");
 }
 
+// src/mat.rs:241-422: the reference's Mat tests with their literal polynomials (ring degree 4 there; the
+// polynomials have degree <= 2, and the expected products are the golden vectors of tests/golden/golden.json)
+static void test_mat() {
+  Params params;
+  Backend<N> be(params);
+  const Poly a00{1, 2, 3}, a01{4, 5, 6}, b00{1, 2}, b10{3, 4};
+  const Mat<N> a({{a00, a01}});            // 1 x 2
+  const Mat<N> b({{b00}, {b10}});          // 2 x 1
+  const Mat<N> c = a.dot(b, be);           // mat.rs:243-268
+  REQUIRE(c.dim() == std::make_pair(size_t(1), size_t(1)));
+  if (N == 4) REQUIRE(c == Mat<N>({{Poly{13, 35, 45, 30}}}));                    // no wrap-around
+  else REQUIRE(c == Mat<N>({{Poly{13, 35, 45, 30}}}));                           // degree 3 < N: same integers
+  const Mat<N> col({{a00}, {a01}});        // 2 x 1
+  REQUIRE(col.add(col, be) == Mat<N>({{Poly{2, 4, 6}}, {Poly{8, 10, 12}}}));     // mat.rs:271-297
+  REQUIRE(col.sub(col, be) == Mat<N>({{Poly{}}, {Poly{}}}));                     // mat.rs:300-326
+  Mat<N> ext = Mat<N>::from_vec({a00});
+  ext.extend_rows(Mat<N>::from_vec({a01}));                                      // mat.rs:329-355
+  REQUIRE(ext == col);
+  Mat<N> wide({{a00}});
+  wide.extend_cols(Mat<N>({{a01}}));                                             // mat.rs:358-386
+  REQUIRE(wide == a);
+  const Mat<N> sq = col.componentwise_mul(a00, be);                              // mat.rs:389-406
+  if (N == 4) REQUIRE(sq == Mat<N>({{Poly{-8, 4, 10, 12}}, {Poly{-14, 13, 28, 27}}}));   // x^4 = -1
+  else REQUIRE(sq == Mat<N>({{Poly{1, 4, 10, 12, 9}}, {Poly{4, 13, 28, 27, 18}}}));      // plain products for N > 4
+  const auto [top, bottom] = col.split_rows(1);                                  // mat.rs:409-422
+  REQUIRE(top == Mat<N>({{a00}}) && bottom == Mat<N>({{a01}}));
+  REQUIRE(Mat<N>::from_element(2, 3, a00).dim() == std::make_pair(size_t(2), size_t(3)));
+  REQUIRE(Mat<N>::diag(2, 2, a00).polynomials[0][1].empty());
+  REQUIRE(col.one_d_mat_to_vec().size() == 2);
+  bool threw = false;
+  try {
+    (void)a.dot(a, be);                    // 1x2 . 1x2: mat.rs:103 panics
+  } catch (const std::runtime_error&) {
+    threw = true;
+  }
+  REQUIRE(threw);
+  std::printf("test_mat ok\n");
+}
+
 // src/params.rs:145-168: standard_deviation KAT, prepare_scalar / prepare_value
 static void test_params() {
   Params params;
@@ -195,6 +234,13 @@ static void test_params() {
 int main(int argc, char** argv) {
   const int iters = argc > 1 ? std::atoi(argv[1]) : 100;   // tests/test.rs: 100 iterations each
   test_params();
+  test_mat();
+  if (const char* only = std::getenv("TEST_ONLY")) {   // "mat": the Mat / Params unit tests alone (N = 4, mat.rs:241)
+    if (std::string(only) == "mat") {
+      std::printf("all ok\n");
+      return 0;
+    }
+  }
   test_open_proof(iters);
   test_linear_proof(iters);
   test_sum_proof(iters);

@@ -11,7 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # 16 is the reference's own test size (tests/test.rs:8); the larger shapes drive the row-group, shared-operand and
 # row-block kernels through the same flows
-@pytest.mark.parametrize("ring_n,shape,iters", [(16, "", 100), (512, "", 100), (512, "2,5,2", 10), (2048, "2,5,2", 2)])
+@pytest.mark.parametrize("ring_n,shape,iters", [(4, "mat-only", 1), (16, "", 100), (512, "", 100), (512, "2,5,2", 10),
+                                                (2048, "2,5,2", 2)])
 def test_cpp_host_mirror_runs_reference_style_tests(tmp_path, ring_n, shape, iters):
     from ring_zk_amd import build
 
@@ -22,7 +23,9 @@ def test_cpp_host_mirror_runs_reference_style_tests(tmp_path, ring_n, shape, ite
                            os.path.join(ROOT, "tests", "cpp", "test_ring_zk.cpp"),
                            "-L" + libdir, "-lrzk_hip", "-Wl,-rpath," + libdir, "-o", exe])
     env = dict(os.environ)
-    if shape:
+    if shape == "mat-only":      # the reference's Mat unit tests run at ring degree 4 (src/mat.rs:241)
+        env["TEST_ONLY"] = "mat"
+    elif shape:
         env["TEST_SHAPE"] = shape
     out = subprocess.run([exe, str(iters)], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stdout + out.stderr

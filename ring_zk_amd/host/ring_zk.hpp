@@ -249,6 +249,44 @@ Poly random_polynomial_from_challenge_set(Rng& rng, size_t kappa) {   // challen
   return p;
 }
 
+// Set difference of the challenge space (challenge_space.rs:39-54, unused by the protocols): c - c' with c != c'
+template <size_t N>
+Poly random_polynomial_from_challenge_set_difference(Rng& rng, size_t kappa) {
+  const Poly c1 = random_polynomial_from_challenge_set<N>(rng, kappa);
+  for (;;) {
+    const Poly c2 = random_polynomial_from_challenge_set<N>(rng, kappa);
+    if (c1 != c2) {
+      Poly d(N);
+      for (size_t i = 0; i < N; ++i) d[i] = c1[i] - c2[i];
+      return d;
+    }
+  }
+}
+
+// ---- norms (src/polynomial.rs:46-88): exact integers; norm_2 is the floor of the square root ---------------------
+inline unsigned __int128 norm_1(const Poly& p) {
+  unsigned __int128 s = 0;
+  for (int64_t c : p) s += (unsigned __int128)(c < 0 ? -(__int128)c : (__int128)c);
+  return s;
+}
+inline uint64_t norm_2(const Poly& p) {
+  unsigned __int128 s = 0;
+  for (int64_t c : p) s += (unsigned __int128)((__int128)c * c);
+  // floor(sqrt(s)) for s < 2^128: Newton from above on 128-bit integers
+  if (s == 0) return 0;
+  unsigned __int128 x = (unsigned __int128)1 << 64, y = (x + s / x) >> 1;
+  while (y < x) {
+    x = y;
+    y = (x + s / x) >> 1;
+  }
+  return (uint64_t)x;
+}
+inline uint64_t norm_infinity(const Poly& p) {
+  uint64_t m = 0;
+  for (int64_t c : p) m = std::max<uint64_t>(m, (uint64_t)(c < 0 ? -(__int128)c : (__int128)c));
+  return m;
+}
+
 // ---- commitment scheme (src/commit.rs) ----------------------------------------------------------------------
 template <size_t N>
 struct Opening {

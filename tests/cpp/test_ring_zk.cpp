@@ -211,6 +211,26 @@ static void test_mat() {
   std::printf("test_mat ok\n");
 }
 
+// src/polynomial.rs:92-132 and src/challenge_space.rs:56-82: samplers and norms
+static void test_polynomial_and_challenge_space() {
+  Rng rng(5);
+  const Poly w = random_polynomial_within<4>(rng, 10);                      // polynomial.rs:98-105
+  for (int64_t c : w) REQUIRE(-10 <= c && c <= 10);
+  const Poly p{1, -2, 3, -4};
+  REQUIRE(norm_1(p) == 10 && norm_2(p) == 5 && norm_infinity(p) == 4);      // polynomial.rs:107-123
+  REQUIRE(norm_2(Poly{3, 4}) == 5 && norm_2(Poly{}) == 0 && norm_2(Poly{1, 1}) == 1);
+  const int64_t half = (Params().modulus - 1) / 2;
+  REQUIRE(norm_2(Poly(2048, half)) == 79542997364ull);                     // floor(sqrt(2048 * half^2)): sum of squares 2^72.4, needs 128 bits
+  const Poly g = random_polynomial_in_normal_distribution<256>(rng, 0.0, 1000.0);   // polynomial.rs:125-131
+  REQUIRE(g.size() == 256 && norm_infinity(g) < 8000);
+  const size_t kappa = 60;                                                   // challenge_space.rs:60-68
+  const Poly c = random_polynomial_from_challenge_set<256>(rng, kappa);
+  REQUIRE(norm_1(c) == kappa && norm_infinity(c) == 1);
+  const Poly dd = random_polynomial_from_challenge_set_difference<256>(rng, kappa);   // challenge_space.rs:70-80
+  for (int64_t v : dd) REQUIRE(v >= -2 && v <= 2);
+  std::printf("test_polynomial_and_challenge_space ok\n");
+}
+
 // src/params.rs:145-168: standard_deviation KAT, prepare_scalar / prepare_value
 static void test_params() {
   Params params;
@@ -234,6 +254,7 @@ static void test_params() {
 int main(int argc, char** argv) {
   const int iters = argc > 1 ? std::atoi(argv[1]) : 100;   // tests/test.rs: 100 iterations each
   test_params();
+  test_polynomial_and_challenge_space();
   test_mat();
   if (const char* only = std::getenv("TEST_ONLY")) {   // "mat": the Mat / Params unit tests alone (N = 4, mat.rs:241)
     if (std::string(only) == "mat") {

@@ -10,8 +10,17 @@
  *
  * Conventions
  *   - A polynomial is N int64 coefficients, each the centred representative in
- *     [-(q-1)/2, (q-1)/2] (what ZqI64<Q> stores; src/params.rs:122-126).  Inputs MUST be in that
- *     range (the reference type guarantees it); outputs always are.
+ *     [-(q-1)/2, (q-1)/2] (what ZqI64<Q> stores; src/params.rs:122-126); outputs always are.  The reference's
+ *     type guarantees this for its own values (ZqI64::from reduces, src/params.rs:126); data from elsewhere
+ *     (the wire, another library) may not be, so EVERY coefficient a kernel loads is tested while it is loaded
+ *     (all 64 bits: k*2^32 + s is never read as s).  A violation
+ *       - in a verifier-side entry point (rzk_*_verify_batch, rzk_commitment_verify_batch) clears the verdict of
+ *         the offending proof (accept / ok = 0) and the call succeeds: a malformed proof is a rejected proof;
+ *       - anywhere else (Mat primitives, commit / response phases) makes the call fail with RZK_E_ARG (the
+ *         host-pointer variants at return, the *_dev variants at the next rzk_ctx_synchronize /
+ *         rzk_ctx_check_inputs); per-proof ok flags of the offending proofs are cleared as well, outputs of
+ *         those proofs are unspecified.  rzk_canonicalize_batch reduces foreign data first (= ZqI64::from);
+ *         rzk_wire_mat_decode rejects out-of-range coefficients when given q.
  *   - Slabs are dense row-major: [batch][row][N].  A "batch" is B independent proofs that share
  *     only the commitment key.
  *   - Every function returns 0 (RZK_OK) or a negative status; nothing aborts.  The Rust shim turns
@@ -61,7 +70,11 @@ void rzk_ctx_destroy(rzk_ctx* ctx);
  * (null) stream.  rzk_ctx_use_own_stream goes back to the private stream created with the context. */
 int rzk_ctx_set_stream(rzk_ctx* ctx, void* hip_stream);
 int rzk_ctx_use_own_stream(rzk_ctx* ctx);
+/* Waits for the context's stream.  Also the point where the asynchronous *_dev calls report non-canonical input
+ * coefficients (see "Conventions"): RZK_E_ARG once, then the condition is cleared.  rzk_ctx_check_inputs is the
+ * same call under the name a caller uses when it only wants that verdict. */
 int rzk_ctx_synchronize(rzk_ctx* ctx);
+int rzk_ctx_check_inputs(rzk_ctx* ctx);
 /* Message of the last failure on this context; with ctx == NULL, of the last failed rzk_ctx_create. */
 const char* rzk_last_error(const rzk_ctx* ctx);
 /* sigma, 4*sigma*floor(sqrt N), 2*sigma*floor(sqrt N)   (src/params.rs:94-98,104,114) */
@@ -96,8 +109,8 @@ int rzk_matvec_batch_dev(rzk_ctx* ctx, int which, const int64_t* v, const int64_
 int rzk_cmul_batch(rzk_ctx* ctx, const int64_t* m, uint32_t rows, const int64_t* p, int64_t* out, size_t B);
 int rzk_cmul_batch_dev(rzk_ctx* ctx, const int64_t* m, uint32_t rows, const int64_t* p, int64_t* out,
                        size_t B);
-/* Any int64 coefficient -> the centred representative in [-(q-1)/2, (q-1)/2] (what ZqI64::from does).  Every
- * other entry point REQUIRES canonical inputs (it reads only the low word of a coefficient); data that did not
+/* Any int64 coefficient -> the centred representative in [-(q-1)/2, (q-1)/2] (what ZqI64::from does,
+ * src/params.rs:126).  Every other entry point rejects non-canonical inputs (see Conventions); data that did not
  * pass through a ZqI64 goes through this first.  in, out: [count][N], may alias. */
 int rzk_canonicalize_batch(rzk_ctx* ctx, const int64_t* in, int64_t* out, size_t count);
 int rzk_canonicalize_batch_dev(rzk_ctx* ctx, const int64_t* in, int64_t* out, size_t count);
@@ -248,12 +261,14 @@ int rzk_sample_challenge_dev(rzk_ctx* ctx, uint64_t seed, uint32_t stream, int64
  * is not pinned by any file of the reference.
  * encode: writes rzk_wire_mat_size() bytes (returned through *written; RZK_E_ARG if cap is too small or a
  *         coefficient does not fit coef_bytes).
- * decode: slab may be NULL to measure only; fails on ragged rows, polynomials longer than N, or truncated
- *         input; *consumed = bytes read, so consecutive fields of a message can be decoded in turn. */
+ * decode: slab may be NULL to measure / validate only; fails on ragged rows, polynomials longer than N, truncated
+ *         input and, with q > 0, on any coefficient outside the centred range [-(q-1)/2, (q-1)/2] of a ZqI64
+ *         (src/params.rs:122-127) — q = 0 decodes plain integers, as the reference's i32 test vector needs;
+ *         *consumed = bytes read, so consecutive fields of a message can be decoded in turn. */
 size_t rzk_wire_mat_size(const int64_t* slab, uint32_t rows, uint32_t cols, uint32_t N, uint32_t coef_bytes);
 int rzk_wire_mat_encode(const int64_t* slab, uint32_t rows, uint32_t cols, uint32_t N, uint32_t coef_bytes,
                         uint8_t* out, size_t cap, size_t* written);
-int rzk_wire_mat_decode(const uint8_t* in, size_t len, uint32_t N, uint32_t coef_bytes, uint32_t* rows,
+int rzk_wire_mat_decode(const uint8_t* in, size_t len, uint32_t N, uint32_t coef_bytes, int64_t q, uint32_t* rows,
                         uint32_t* cols, int64_t* slab, size_t slab_polys, size_t* consumed);
 
 /* HIP-event timing of the last phase call's dominant kernel is exposed through these counters:

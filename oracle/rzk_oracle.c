@@ -75,22 +75,18 @@ static uint64_t isqrt_u128(u128 x) {
 void rzko_poly_mul(int64_t q, uint32_t N, const int64_t* a, const int64_t* b, int64_t* out) {
   /* Polynomial::mul in Z_q[X]/(X^N+1) (call sites mat.rs:110, mat.rs:176, linear.rs:94):
    * c_t = sum_{i+j=t} a_i b_j - sum_{i+j=t+N} a_i b_j.  Exact: |a_i b_j| < 2^62 for centred
-   * inputs mod a 32-bit q, N <= 2^16 terms -> < 2^78, held in __int128. */
-  i128* acc = (i128*)calloc(N, sizeof(i128));
-  for (uint32_t i = 0; i < N; ++i) {
-    i128 ai = a[i];
-    if (ai == 0) continue;
-    for (uint32_t j = 0; j < N; ++j) {
-      uint32_t t = i + j;
-      i128 prod = ai * (i128)b[j];
-      if (t < N)
-        acc[t] += prod;
-      else
-        acc[t - N] -= prod;
-    }
+   * inputs mod a 32-bit q, N <= 2^16 terms -> < 2^78, held in __int128.
+   * Large ring degrees called from serial code (the single-proof checks of the big BASELINE shapes) spread the
+   * output coefficients over the host threads; inside rzko_open_cycle_batch (already parallel over proofs)
+   * the loop stays serial.  Same sums either way: every c_t is one exact integer. */
+  const int par = N >= 1024 && !omp_in_parallel();
+#pragma omp parallel for schedule(static) if (par)
+  for (uint32_t t = 0; t < N; ++t) {
+    i128 acc = 0;
+    for (uint32_t i = 0; i <= t; ++i) acc += (i128)a[i] * (i128)b[t - i];
+    for (uint32_t i = t + 1; i < N; ++i) acc -= (i128)a[i] * (i128)b[t + N - i];
+    out[t] = center128(acc, q);
   }
-  for (uint32_t t = 0; t < N; ++t) out[t] = center128(acc[t], q);
-  free(acc);
 }
 
 void rzko_poly_add(int64_t q, uint32_t N, const int64_t* a, const int64_t* b, int64_t* out) {

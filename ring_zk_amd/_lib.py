@@ -27,6 +27,7 @@ SIGNATURES = {
     "rzk_ctx_set_stream": (C.c_int, [_CTX, C.c_void_p]),
     "rzk_ctx_use_own_stream": (C.c_int, [_CTX]),
     "rzk_ctx_synchronize": (C.c_int, [_CTX]),
+    "rzk_ctx_check_inputs": (C.c_int, [_CTX]),
     "rzk_last_error": (C.c_char_p, [_CTX]),
     "rzk_sigma": (C.c_uint64, [_CTX]),
     "rzk_commit_bound": (C.c_uint64, [_CTX]),
@@ -64,8 +65,8 @@ SIGNATURES = {
     "rzk_wire_mat_size": (C.c_size_t, [_I64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "rzk_wire_mat_encode": (C.c_int, [_I64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _U8, _SZ,
                                       C.POINTER(C.c_size_t)]),
-    "rzk_wire_mat_decode": (C.c_int, [_U8, _SZ, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
-                                      _I64, _SZ, C.POINTER(C.c_size_t)]),
+    "rzk_wire_mat_decode": (C.c_int, [_U8, _SZ, C.c_uint32, C.c_uint32, C.c_int64, C.POINTER(C.c_uint32),
+                                      C.POINTER(C.c_uint32), _I64, _SZ, C.POINTER(C.c_size_t)]),
     "rzk_bench_ntt_forward_dev": (C.c_double, [_CTX, C.c_int, _U32P, _U32P, _SZ, C.c_int]),
     "rzk_prof_reset": (C.c_int, [_CTX]),
     "rzk_prof_enable": (C.c_int, [_CTX, C.c_int]),

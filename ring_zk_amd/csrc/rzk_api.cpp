@@ -99,6 +99,11 @@ struct rzk_ctx {
   double* d_key_inf = nullptr;
   std::map<std::pair<int, uint32_t>, DevProg> progs;
   Arena ws, stage, ws_slots;
+  // canonical-input test (rzk_dev.h, Operands::bad): sticky word set by any kernel that loaded a coefficient
+  // outside the centred range on behalf of an entry point without per-proof verdicts; read back at every
+  // synchronising call (host-pointer variants, rzk_ctx_synchronize, rzk_ctx_check_inputs)
+  uint32_t* d_bad = nullptr;
+  uint32_t* h_bad = nullptr;   // pinned
   double slot_share_min = 2.0;   // use the shared-operand path when (operand transforms) / (distinct operands) >= this
   std::string err;
   // profiling of the row kernel with HIP events on the launch stream
@@ -679,8 +684,10 @@ struct OpSpec {
 };
 
 // `group` > 1: the batch is B*group (proof, summand) pairs; operands with outer != 0 and the flags are per proof
+// sticky: a non-canonical input coefficient fails the CALL (prover-side / Mat-level entry points); verifier-side
+// programs pass false — there the offending proof's verdict flag is cleared and the call succeeds.
 int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& specs, uint8_t* flags,
-                uint32_t group, uint64_t batch, uint64_t norm_limit = 0) {
+                uint32_t group, uint64_t batch, uint64_t norm_limit = 0, bool sticky = true) {
   DevProg dp;
   int rc = get_program(c, id, var, dp);
   if (rc != RZK_OK) return rc;
@@ -694,6 +701,7 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
   ops.group = group ? group : 1;
   ops.pad = dp.two_bit ? 1 : 0;
   ops.norm_limit = norm_limit;
+  ops.bad = sticky ? c->d_bad : nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->prof) {
     if (c->prof_used == c->prof_events.size()) {
@@ -784,7 +792,8 @@ uint64_t fused_limit(const rzk_ctx* c, uint64_t bound) {
 // Runs the checked variant (var | 1) of a program with the norm predicate fused into it: flags are
 // preset to 1 and cleared by failing rows.  Returns RZK_E_UNSUPPORTED when fusion is not possible.
 int run_program_checked(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& specs, uint8_t* flags,
-                        uint32_t group, uint64_t batch, uint64_t nflags, uint64_t bound, bool preset = true) {
+                        uint32_t group, uint64_t batch, uint64_t nflags, uint64_t bound, bool preset = true,
+                        bool sticky = true) {
   const uint64_t lim = fused_limit(c, bound);
   if (!lim || !flags) return RZK_E_UNSUPPORTED;
   DevProg dp;
@@ -797,7 +806,7 @@ int run_program_checked(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSp
     rc = check_launch(c, launch_fill_u8(cfg_of(c), flags, all_ok, nflags), "flag preset");
     if (rc != RZK_OK) return rc;
   }
-  return run_program(c, id, var | 1, specs, flags, group, batch, lim);
+  return run_program(c, id, var | 1, specs, flags, group, batch, lim, sticky);
 }
 
 bool can_fuse(rzk_ctx* c, int id, uint32_t var, uint64_t bound) {
@@ -806,14 +815,17 @@ bool can_fuse(rzk_ctx* c, int id, uint32_t var, uint64_t bound) {
 }
 
 int run_norm(rzk_ctx* c, const int64_t* v, uint32_t rows, uint64_t bound, uint8_t* ok, uint64_t B, int mode,
-             int shift) {
+             int shift, bool sticky = true) {
   // canonical coefficients are below 2^31 in magnitude, so sum c^2 < 2^73: every bound from 2^37 on holds for
   // all inputs; clamping there keeps (bound+1)^2 inside 128 bits for any u64 bound (sigma grows with b)
   if (bound > (1ull << 40)) bound = 1ull << 40;
   uint64_t hi, lo;
   norm_limit(bound, hi, lo);
-  if (c->small) return check_launch(c, launch_norm_small(c->N, cfg_of(c), v, rows, hi, lo, ok, B, mode, shift), "norm kernel");
-  return check_launch(c, launch_norm((int)c->logn, cfg_of(c), v, rows, hi, lo, ok, B, mode, shift), "norm kernel");
+  uint32_t* bad = sticky ? c->d_bad : nullptr;
+  const uint32_t qh = c->hT.crt.qhalf;
+  if (c->small)
+    return check_launch(c, launch_norm_small(c->N, cfg_of(c), v, rows, hi, lo, ok, B, mode, shift, qh, bad), "norm kernel");
+  return check_launch(c, launch_norm((int)c->logn, cfg_of(c), v, rows, hi, lo, ok, B, mode, shift, qh, bad), "norm kernel");
 }
 
 // ---- host-pointer plumbing ---------------------------------------------------------------------------------
@@ -838,11 +850,22 @@ int stage_in(rzk_ctx* c, std::vector<HostBuf>& bufs) {
   return RZK_OK;
 }
 
+// Synchronises and reports (then clears) the sticky input-error word.
+int take_input_error(rzk_ctx* c) {
+  HIPCHK(c, hipMemcpyAsync(c->h_bad, c->d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (*c->h_bad == 0) return RZK_OK;
+  *c->h_bad = 0;
+  HIPCHK(c, hipMemsetAsync(c->d_bad, 0, sizeof(uint32_t), c->stream));
+  return fail(c, RZK_E_ARG,
+              "an input coefficient is not the centred representative in [-(q-1)/2, (q-1)/2] (ZqI64 range); "
+              "reduce foreign data with rzk_canonicalize_batch first");
+}
+
 int stage_out(rzk_ctx* c, std::vector<HostBuf>& bufs) {
   for (auto& b : bufs)
     if (b.out && b.bytes) HIPCHK(c, hipMemcpyAsync(b.out, b.dev, b.bytes, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return RZK_OK;
+  return take_input_error(c);
 }
 
 size_t polys(const rzk_ctx* c, size_t count) { return count * (size_t)c->N * sizeof(int64_t); }
@@ -927,6 +950,10 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
                                       row_scratch_words((int)c->logn, c->num_cus) * sizeof(uint32_t)) == hipSuccess);
   okk = okk && hipMalloc((void**)&c->dT, sizeof(DevTables)) == hipSuccess &&
         hipMemcpy(c->dT, &c->hT, sizeof(DevTables), hipMemcpyHostToDevice) == hipSuccess;
+  okk = okk && hipMalloc((void**)&c->d_bad, sizeof(uint32_t)) == hipSuccess &&
+        hipMemset(c->d_bad, 0, sizeof(uint32_t)) == hipSuccess &&
+        hipHostMalloc((void**)&c->h_bad, sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+  if (okk) *c->h_bad = 0;
   if (!okk) {
     rzk_ctx_destroy(c);
     return create_fail(RZK_E_HIP, std::string("table upload: ") + hipGetErrorString(hipGetLastError()));
@@ -955,6 +982,8 @@ void rzk_ctx_destroy(rzk_ctx* c) {
   if (c->d_block_scratch) (void)hipFree(c->d_block_scratch);
   if (c->d_group_scratch) (void)hipFree(c->d_group_scratch);
   if (c->d_key_mont) (void)hipFree(c->d_key_mont);
+  if (c->d_bad) (void)hipFree(c->d_bad);
+  if (c->h_bad) (void)hipHostFree(c->h_bad);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -975,9 +1004,11 @@ int rzk_ctx_use_own_stream(rzk_ctx* c) {
 
 int rzk_ctx_synchronize(rzk_ctx* c) {
   if (!c) return RZK_E_ARG;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return RZK_OK;
+  (void)hipSetDevice(c->device);
+  return take_input_error(c);   // also the place where the asynchronous *_dev calls report non-canonical inputs
 }
+
+int rzk_ctx_check_inputs(rzk_ctx* c) { return rzk_ctx_synchronize(c); }
 
 const char* rzk_last_error(const rzk_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 uint64_t rzk_sigma(const rzk_ctx* c) { return c ? c->sigma : 0; }
@@ -1143,13 +1174,13 @@ int rzk_canonicalize_batch_dev(rzk_ctx* c, const int64_t* in, int64_t* out, size
 int rzk_add_batch_dev(rzk_ctx* c, const int64_t* a, const int64_t* b, int64_t* out, size_t count) {
   if (c && count == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !a || !b || !out) return RZK_E_ARG;
-  return check_launch(c, launch_addsub(cfg_of(c), false, a, b, out, (uint64_t)count * c->N, c->dT), "add kernel");
+  return check_launch(c, launch_addsub(cfg_of(c), false, a, b, out, (uint64_t)count * c->N, c->dT, c->d_bad), "add kernel");
 }
 
 int rzk_sub_batch_dev(rzk_ctx* c, const int64_t* a, const int64_t* b, int64_t* out, size_t count) {
   if (c && count == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !a || !b || !out) return RZK_E_ARG;
-  return check_launch(c, launch_addsub(cfg_of(c), true, a, b, out, (uint64_t)count * c->N, c->dT), "sub kernel");
+  return check_launch(c, launch_addsub(cfg_of(c), true, a, b, out, (uint64_t)count * c->N, c->dT, c->d_bad), "sub kernel");
 }
 
 int rzk_norm2_le_batch_dev(rzk_ctx* c, const int64_t* v, uint32_t rows, uint64_t bound, uint8_t* ok, size_t B) {
@@ -1161,8 +1192,9 @@ int rzk_norm2_le_batch_dev(rzk_ctx* c, const int64_t* v, uint32_t rows, uint64_t
 int rzk_eq_batch_dev(rzk_ctx* c, const int64_t* a, const int64_t* b, uint32_t rows, uint8_t* eq, size_t B) {
   if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || !a || !b || !eq || rows == 0) return RZK_E_ARG;
-  if (c->small) return check_launch(c, launch_eq_small(c->N, cfg_of(c), a, b, rows, eq, B), "eq kernel");
-  return check_launch(c, launch_eq((int)c->logn, cfg_of(c), a, b, rows, eq, B), "eq kernel");
+  const uint32_t qh = c->hT.crt.qhalf;
+  if (c->small) return check_launch(c, launch_eq_small(c->N, cfg_of(c), a, b, rows, eq, B, qh, c->d_bad), "eq kernel");
+  return check_launch(c, launch_eq((int)c->logn, cfg_of(c), a, b, rows, eq, B, qh, c->d_bad), "eq kernel");
 }
 
 int rzk_ntt_forward_batch_dev(rzk_ctx* c, int prime, const uint32_t* in, uint32_t* out, size_t count) {
@@ -1227,20 +1259,21 @@ int run_a1_relation(rzk_ctx* c, const std::vector<OpSpec>& specs, int64_t* w, ui
   int rc;
   if (split) {
     const std::vector<OpSpec> a1z = {specs[0], {w, c->n, 0}};
-    rc = run_program_checked(c, PG_A1Z, 0, a1z, accept, group, batch, nflags, c->verify_bound, preset);
+    // verifier side: non-canonical prover data clears the proof's verdict, the call itself succeeds (sticky = false)
+    rc = run_program_checked(c, PG_A1Z, 0, a1z, accept, group, batch, nflags, c->verify_bound, preset, false);
     if (rc == RZK_E_UNSUPPORTED) {
-      rc = run_norm(c, specs[0].base, group * c->k, c->verify_bound, accept, nflags, preset ? 0 : 1, 0);
+      rc = run_norm(c, specs[0].base, group * c->k, c->verify_bound, accept, nflags, preset ? 0 : 1, 0, false);
       if (rc != RZK_OK) return rc;
-      rc = run_program(c, PG_A1Z, 0, a1z, nullptr, group, batch);
+      rc = run_program(c, PG_A1Z, 0, a1z, accept, group, batch, 0, false);
     }
     if (rc != RZK_OK) return rc;
-    return run_program(c, PG_REL_ROT, 0, {{w, c->n, 0}, specs[1], specs[2], specs[3]}, accept, group, batch);
+    return run_program(c, PG_REL_ROT, 0, {{w, c->n, 0}, specs[1], specs[2], specs[3]}, accept, group, batch, 0, false);
   }
-  rc = run_program_checked(c, PG_A1_RELATION, 0, specs, accept, group, batch, nflags, c->verify_bound, preset);
+  rc = run_program_checked(c, PG_A1_RELATION, 0, specs, accept, group, batch, nflags, c->verify_bound, preset, false);
   if (rc != RZK_E_UNSUPPORTED) return rc;
-  rc = run_norm(c, specs[0].base, group * c->k, c->verify_bound, accept, nflags, preset ? 0 : 1, 0);
+  rc = run_norm(c, specs[0].base, group * c->k, c->verify_bound, accept, nflags, preset ? 0 : 1, 0, false);
   if (rc != RZK_OK) return rc;
-  return run_program(c, PG_A1_RELATION, 0, specs, accept, group, batch);
+  return run_program(c, PG_A1_RELATION, 0, specs, accept, group, batch, 0, false);
 }
 
 }  // namespace
@@ -1254,10 +1287,10 @@ int rzk_commit_batch_dev(rzk_ctx* c, const int64_t* x, const int64_t* r, int64_t
   const std::vector<OpSpec> specs = {{x, c->l, 0}, {r, c->k, 0}, {cm, c->n + c->l, 0}};
   int rc = run_program_checked(c, PG_COMMIT, 0, specs, ok, 1, B, B, c->commit_bound);
   if (rc != RZK_E_UNSUPPORTED) return rc;
-  rc = run_program(c, PG_COMMIT, 0, specs, nullptr, 1, B);
-  if (rc != RZK_OK) return rc;
+  // unfused: the exact norm kernel sets ok, then the rows clear it again for proofs with non-canonical inputs
   if (ok) rc = run_norm(c, r, c->k, c->commit_bound, ok, B, 0, 0);
-  return rc;
+  if (ok && rc != RZK_OK) return rc;
+  return run_program(c, PG_COMMIT, 0, specs, ok, 1, B);
 }
 
 int rzk_commitment_verify_batch_dev(rzk_ctx* c, const int64_t* cm, const int64_t* x, const int64_t* r,
@@ -1267,11 +1300,11 @@ int rzk_commitment_verify_batch_dev(rzk_ctx* c, const int64_t* cm, const int64_t
   const uint32_t var = f ? 2u : 0u;
   const std::vector<OpSpec> specs = {{x, c->l, 0}, {r, c->k, 0}, {cm, c->n + c->l, 0}, {f, 1, 0}};
   // commit.rs:183-185: the norm predicate on r rides on the rows that load r
-  int rc = run_program_checked(c, PG_COMMIT_VERIFY, var, specs, ok, 1, B, B, c->commit_bound);
+  int rc = run_program_checked(c, PG_COMMIT_VERIFY, var, specs, ok, 1, B, B, c->commit_bound, true, false);
   if (rc != RZK_E_UNSUPPORTED) return rc;
-  rc = run_norm(c, r, c->k, c->commit_bound, ok, B, 0, 0);
+  rc = run_norm(c, r, c->k, c->commit_bound, ok, B, 0, 0, false);
   if (rc != RZK_OK) return rc;
-  return run_program(c, PG_COMMIT_VERIFY, var, specs, ok, 1, B);
+  return run_program(c, PG_COMMIT_VERIFY, var, specs, ok, 1, B, 0, false);
 }
 
 // =================================================================================================
@@ -1285,10 +1318,9 @@ int rzk_open_commit_batch_dev(rzk_ctx* c, const int64_t* x, const int64_t* r, co
   // check_commit_constraint(r) (params.rs:102-108) rides on the loads of r the commit rows do anyway
   int rc = run_program_checked(c, PG_OPEN_COMMIT, 0, specs, ok, 1, B, B, c->commit_bound);
   if (rc != RZK_E_UNSUPPORTED) return rc;
-  rc = run_program(c, PG_OPEN_COMMIT, 0, specs, nullptr, 1, B);
-  if (rc != RZK_OK) return rc;
   if (ok) rc = run_norm(c, r, c->k, c->commit_bound, ok, B, 0, 0);
-  return rc;
+  if (ok && rc != RZK_OK) return rc;
+  return run_program(c, PG_OPEN_COMMIT, 0, specs, ok, 1, B);
 }
 
 int rzk_open_response_batch_dev(rzk_ctx* c, const int64_t* y, const int64_t* r, const int64_t* d, int64_t* z,
@@ -1336,17 +1368,16 @@ int rzk_linear_commit_batch_dev(rzk_ctx* c, const int64_t* g, const int64_t* x, 
     fused = rc == RZK_OK;
   }
   if (!fused) {
-    rc = run_program(c, PG_LIN_COMMIT2, 0, c2, nullptr, 1, B);
+    if (ok) {   // bit 0: constraint(r), bit 1: constraint(rp); the rows below clear the byte on non-canonical inputs
+      rc = run_norm(c, r, k, c->commit_bound, ok, B, 0, 0);
+      if (rc != RZK_OK) return rc;
+      rc = run_norm(c, rp, k, c->commit_bound, ok, B, 2, 1);
+      if (rc != RZK_OK) return rc;
+    }
+    rc = run_program(c, PG_LIN_COMMIT2, 0, c2, ok, 1, B);
     if (rc != RZK_OK) return rc;
   }
-  rc = run_program(c, PG_LIN_U, 0, {{a2y, l, 0}, {g, 1, 0}, {yp, k, 0}, {u, l, 0}}, nullptr, 1, B);
-  if (rc != RZK_OK) return rc;
-  if (ok && !fused) {
-    rc = run_norm(c, r, k, c->commit_bound, ok, B, 0, 0);
-    if (rc != RZK_OK) return rc;
-    rc = run_norm(c, rp, k, c->commit_bound, ok, B, 2, 1);
-  }
-  return rc;
+  return run_program(c, PG_LIN_U, 0, {{a2y, l, 0}, {g, 1, 0}, {yp, k, 0}, {u, l, 0}}, ok, 1, B);
 }
 
 int rzk_linear_response_batch_dev(rzk_ctx* c, const int64_t* y, const int64_t* yp, const int64_t* r,
@@ -1372,16 +1403,17 @@ int rzk_linear_verify_batch_dev(rzk_ctx* c, const int64_t* z, const int64_t* zp,
   const std::vector<OpSpec> v1 = {{z, k, 0}, {zp, k, 0}, {t, n, 0}, {tp, n, 0}, {cm, n + l, 0}, {cpm, n + l, 0},
                                   {d, 1, 0}, {g, 1, 0}, {w1, l, 0}, {w2, l, 0}};
   // linear.rs:218-223: norm predicates on z and zp, fused into the rows that load them when possible
-  rc = run_program_checked(c, PG_LIN_V1, 0, v1, accept, 1, B, B, c->verify_bound);
+  rc = run_program_checked(c, PG_LIN_V1, 0, v1, accept, 1, B, B, c->verify_bound, true, false);
   if (rc == RZK_E_UNSUPPORTED) {
-    rc = run_norm(c, z, k, c->verify_bound, accept, B, 0, 0);
+    rc = run_norm(c, z, k, c->verify_bound, accept, B, 0, 0, false);
     if (rc != RZK_OK) return rc;
-    rc = run_norm(c, zp, k, c->verify_bound, accept, B, 1, 0);
+    rc = run_norm(c, zp, k, c->verify_bound, accept, B, 1, 0, false);
     if (rc != RZK_OK) return rc;
-    rc = run_program(c, PG_LIN_V1, 0, v1, accept, 1, B);
+    rc = run_program(c, PG_LIN_V1, 0, v1, accept, 1, B, 0, false);
   }
   if (rc != RZK_OK) return rc;
-  return run_program(c, PG_LIN_V2, 0, {{w1, l, 0}, {w2, l, 0}, {g, 1, 0}, {d, 1, 0}, {zp, k, 0}, {u, l, 0}}, accept, 1, B);
+  return run_program(c, PG_LIN_V2, 0, {{w1, l, 0}, {w2, l, 0}, {g, 1, 0}, {d, 1, 0}, {zp, k, 0}, {u, l, 0}}, accept, 1, B, 0,
+                     false);
 }
 
 // =================================================================================================
@@ -1398,6 +1430,8 @@ int rzk_sum_commit_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* gs, const in
   int64_t* xp = (int64_t*)c->ws.p;
   int64_t* w = xp + B * l * c->N;
   // sum.rs:107-115: xp = sum_i x_i (.) g_i
+  // (XP runs before ok is preset: a non-canonical x_i / g_i is reported through the sticky word, and again by the
+  //  later rows that load the same polynomials with the flags in place)
   rc = run_program(c, PG_SUM_XP, V, {{xs, V * l, 0}, {gs, V, 0}, {xp, l, 0}}, nullptr, 1, B);
   if (rc != RZK_OK) return rc;
   // sum.rs:116 and 151: cp = commit(xp; rp), tp = a1.yp
@@ -1412,22 +1446,21 @@ int rzk_sum_commit_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* gs, const in
     rc = run_program_checked(c, PG_OPEN_COMMIT, 0, cs_specs, ok, V, B * V, B, c->commit_bound, false);
     if (rc != RZK_OK) return rc;
   } else {
-    rc = run_program(c, PG_OPEN_COMMIT, 0, cp_specs, nullptr, 1, B);
+    if (ok) {
+      rc = run_norm(c, rp, k, c->commit_bound, ok, B, 0, 0);
+      if (rc != RZK_OK) return rc;
+      rc = run_norm(c, rs, V * k, c->commit_bound, ok, B, 1, 0);
+      if (rc != RZK_OK) return rc;
+    }
+    rc = run_program(c, PG_OPEN_COMMIT, 0, cp_specs, ok, 1, B);
     if (rc != RZK_OK) return rc;
-    rc = run_program(c, PG_OPEN_COMMIT, 0, cs_specs, nullptr, 1, B * V);
+    rc = run_program(c, PG_OPEN_COMMIT, 0, cs_specs, ok, V, B * V);
     if (rc != RZK_OK) return rc;
   }
   // sum.rs:154-160: u = sum_i (a2.y_i)(.)g_i - a2.yp
   rc = run_program(c, PG_MATVEC, RZK_KEY_A2 * 2, {{ys, k, 0}, {nullptr, l, 0}, {w, l, 0}}, nullptr, 1, B * V);
   if (rc != RZK_OK) return rc;
-  rc = run_program(c, PG_SUM_U, V, {{w, V * l, 0}, {gs, V, 0}, {yp, k, 0}, {u, l, 0}}, nullptr, 1, B);
-  if (rc != RZK_OK) return rc;
-  if (ok && !fused) {
-    rc = run_norm(c, rp, k, c->commit_bound, ok, B, 0, 0);
-    if (rc != RZK_OK) return rc;
-    rc = run_norm(c, rs, V * k, c->commit_bound, ok, B, 1, 0);
-  }
-  return rc;
+  return run_program(c, PG_SUM_U, V, {{w, V * l, 0}, {gs, V, 0}, {yp, k, 0}, {u, l, 0}}, ok, 1, B);
 }
 
 int rzk_sum_response_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* ys, const int64_t* yp, const int64_t* rs,
@@ -1463,12 +1496,12 @@ int rzk_sum_verify_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* zs, const in
   rc = run_a1_relation(c, rel_p, w0, accept, 1, B, B, false);
   if (rc != RZK_OK) return rc;
   // sum.rs:301-319
-  rc = run_program(c, PG_MATVEC, RZK_KEY_A2 * 2, {{zs, k, 0}, {nullptr, l, 0}, {w1, l, 0}}, nullptr, 1, B * V);
+  rc = run_program(c, PG_MATVEC, RZK_KEY_A2 * 2, {{zs, k, 0}, {nullptr, l, 0}, {w1, l, 0}}, accept, V, B * V, 0, false);
   if (rc != RZK_OK) return rc;
-  rc = run_program(c, PG_SUM_W2, V, {{cs, V * (n + l), 0}, {gs, V, 0}, {cpm, n + l, 0}, {w2, l, 0}}, nullptr, 1, B);
+  rc = run_program(c, PG_SUM_W2, V, {{cs, V * (n + l), 0}, {gs, V, 0}, {cpm, n + l, 0}, {w2, l, 0}}, accept, 1, B, 0, false);
   if (rc != RZK_OK) return rc;
   return run_program(c, PG_SUM_V3, V, {{w1, V * l, 0}, {gs, V, 0}, {zp, k, 0}, {w2, l, 0}, {d, 1, 0}, {u, l, 0}}, accept,
-                     1, B);
+                     1, B, 0, false);
 }
 
 // =================================================================================================

@@ -120,6 +120,10 @@ struct Operands {
   uint32_t group;
   uint32_t pad;          // != 0: two-bit verdict flags (TERM_CHECK clears bit 0, TERM_CHECK2 bit 1; row_kernel only)
   uint64_t norm_limit;   // (bound+1)^2 of the fused norm predicate; must be <= 2^48 (0 = unused)
+  // Canonical-input test (every coefficient a kernel loads must be the centred representative a ZqI64 holds,
+  // src/params.rs:122-127): a violation clears the proof's verdict flag when the launch has flags, and sets this
+  // sticky word of the context when it is not NULL (prover-side and Mat-level entry points: the call fails).
+  uint32_t* bad;
 };
 
 // ---- launchers (defined in rzk_kernels.hip) --------------------------------------------------------------------
@@ -169,13 +173,15 @@ int launch_sample_challenge(const LaunchCfg& cfg, int64_t* out, uint64_t npoly, 
                             uint32_t stream, uint32_t kappa);
 int launch_canonicalize(const LaunchCfg& cfg, const int64_t* in, int64_t* out, uint64_t ncoef, int64_t q);
 int launch_addsub(const LaunchCfg& cfg, bool sub, const int64_t* a, const int64_t* b, int64_t* out,
-                  uint64_t ncoef, const DevTables* d_T);
+                  uint64_t ncoef, const DevTables* d_T, uint32_t* bad_word);
 // ok[b] = (all `rows` polys of proof b have sum c^2 < limit), limit = (bound+1)^2 given as hi:lo.
 // and_mode: 0 = overwrite ok[b], 1 = ok[b] &= result, 2 = ok[b] |= result << shift
+// qhalf = (q-1)/2, bad_word: see Operands::bad (a non-canonical coefficient also fails the predicate / equality)
 int launch_norm(int logn, const LaunchCfg& cfg, const int64_t* v, uint32_t rows, uint64_t limit_hi,
-                uint64_t limit_lo, uint8_t* ok, uint64_t B, int and_mode, int shift);
+                uint64_t limit_lo, uint8_t* ok, uint64_t B, int and_mode, int shift, uint32_t qhalf,
+                uint32_t* bad_word);
 int launch_eq(int logn, const LaunchCfg& cfg, const int64_t* a, const int64_t* b, uint32_t rows,
-              uint8_t* eq, uint64_t B);
+              uint8_t* eq, uint64_t B, uint32_t qhalf, uint32_t* bad_word);
 // small ring degrees (N = 4 .. 256): schoolbook products mod q, same row programs
 int launch_row_program_small(uint32_t N, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows,
                              const Operands& ops, const uint32_t* d_key_mont, const DevTables* d_T, uint32_t r2q,
@@ -183,8 +189,9 @@ int launch_row_program_small(uint32_t N, const LaunchCfg& cfg, const Program* d_
 int launch_key_mont(const LaunchCfg& cfg, const int64_t* d_key, uint32_t* d_key_mont, uint64_t ncoef,
                     const DevTables* d_T, uint32_t r2q);
 int launch_norm_small(uint32_t N, const LaunchCfg& cfg, const int64_t* v, uint32_t rows, uint64_t limit_hi,
-                      uint64_t limit_lo, uint8_t* ok, uint64_t B, int and_mode, int shift);
+                      uint64_t limit_lo, uint8_t* ok, uint64_t B, int and_mode, int shift, uint32_t qhalf,
+                      uint32_t* bad_word);
 int launch_eq_small(uint32_t N, const LaunchCfg& cfg, const int64_t* a, const int64_t* b, uint32_t rows,
-                    uint8_t* eq, uint64_t B);
+                    uint8_t* eq, uint64_t B, uint32_t qhalf, uint32_t* bad_word);
 
 }  // namespace rzk

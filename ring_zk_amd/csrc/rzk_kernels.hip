@@ -90,15 +90,58 @@ __device__ __forceinline__ void fail_check(uint8_t* flag, bool two_bit, bool sec
                          __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---- canonical-input test ---------------------------------------------------------------------------------
+// A coefficient at the boundary is the centred representative a ZqI64 holds (src/params.rs:122-127): an int64 in
+// [-(q-1)/2, (q-1)/2].  The arithmetic below only uses the low word, so every load also proves that the word it
+// drops carries no information: with h = (q-1)/2, c is canonical  <=>  (uint64)(c + h) <= q - 1.  The 64-bit add
+// is one v_lshl_add_u64; its high word is OR-ed into `bad`, its low word max-ed into `mx` (or, where the 1-norm
+// pass already has max |lo|, that is compared with h instead).  A kappa*2^32 + s coefficient is therefore never
+// read as s: the proof's verdict flag is cleared and / or the context's sticky input-error word is set.
+__device__ __forceinline__ int32_t canon_lo(int64_t c, uint32_t qhalf, uint32_t& bad) {
+  bad |= (uint32_t)(((uint64_t)c + qhalf) >> 32);
+  return (int32_t)c;
+}
+__device__ __forceinline__ int32_t canon_lo_mx(int64_t c, uint32_t qhalf, uint32_t& bad, uint32_t& mx) {
+  const uint64_t s = (uint64_t)c + qhalf;
+  bad |= (uint32_t)(s >> 32);
+  const uint32_t lo = (uint32_t)s;
+  mx = lo > mx ? lo : mx;
+  return (int32_t)c;
+}
+// the same for a 16-byte load of two coefficients (lo0, hi0, lo1, hi1)
+__device__ __forceinline__ void canon_pair(const int4 t, uint32_t qhalf, uint32_t& bad, uint32_t& mx) {
+  const uint64_t s0 = (((uint64_t)(uint32_t)t.y << 32) | (uint32_t)t.x) + qhalf;
+  const uint64_t s1 = (((uint64_t)(uint32_t)t.w << 32) | (uint32_t)t.z) + qhalf;
+  bad |= (uint32_t)(s0 >> 32) | (uint32_t)(s1 >> 32);
+  const uint32_t l0 = (uint32_t)s0, l1 = (uint32_t)s1;
+  mx = l0 > mx ? l0 : mx;
+  mx = l1 > mx ? l1 : mx;
+}
+// wave-uniform verdict of the per-lane accumulators (mx holds max (lo + h) mod 2^32, canonical <=> <= 2h)
+__device__ __forceinline__ bool canon_fail(uint32_t bad, uint32_t mx, uint32_t qhalf) {
+  return __any((bad != 0) | (mx > 2u * qhalf)) != 0;
+}
+// A non-canonical coefficient was loaded for proof `bo`: clear its verdict (all bits) and raise the sticky word.
+__device__ __forceinline__ void input_fault(const Operands& ops, uint8_t* flags, uint32_t bo, int lane) {
+  if (lane != 0) return;
+  if (flags) {
+    if (ops.pad) {
+      const uintptr_t a = reinterpret_cast<uintptr_t>(flags + bo);
+      __hip_atomic_fetch_and(reinterpret_cast<uint32_t*>(a & ~(uintptr_t)3), ~(0xffu << (8u * (uint32_t)(a & 3u))),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      flags[bo] = 0;
+    }
+  }
+  if (ops.bad) *ops.bad = 1u;
+}
+
 __device__ __forceinline__ const int64_t* operand_ptr(const Operands& ops, uint32_t op, uint32_t off,
                                                        uint32_t b, uint32_t bo, int n_coef) {
   const uint32_t idx = ops.outer[op] ? bo : b;
   return ops.base[op] + ((uint64_t)idx * ops.stride[op] + off) * (uint64_t)n_coef;
 }
 
-#ifndef RZK_LOAD_LO32
-#define RZK_LOAD_LO32 0   // 1: fetch only the low dword of each int64 coefficient (measured: no gain)
-#endif
 #ifndef RZK_EPI_CHUNK
 #define RZK_EPI_CHUNK 16  // coefficients per lane handled together in the epilogue (4 was slower: fewer loads in flight)
 #endif
@@ -123,18 +166,15 @@ __device__ __forceinline__ const int64_t* operand_ptr(const Operands& ops, uint3
 template <int LOGN>
 __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict__ src, int lane,
                                           const PrimeConsts& pc, bool want_norms, double& l1, double& linf,
-                                          bool want_sq, uint64_t& sumsq) {
+                                          bool want_sq, uint64_t& sumsq, uint32_t qhalf, bool& fault) {
   using G = Geo<LOGN>;
   int32_t v[G::E];
-#if RZK_LOAD_LO32
-  const int32_t* __restrict__ lo = reinterpret_cast<const int32_t*>(src);
-#pragma unroll
-  for (int e = 0; e < G::E; ++e) v[e] = lo[2 * G::j_p1(lane, e)];
-#else
-#pragma unroll
-  for (int e = 0; e < G::E; ++e) v[e] = (int32_t)src[G::j_p1(lane, e)];
-#endif
   if (want_norms) {
+    // first prime pass: the loads also prove that the coefficients are canonical (canon_lo) and measure the
+    // polynomial; later passes re-read the low words only
+    uint32_t bad = 0;
+#pragma unroll
+    for (int e = 0; e < G::E; ++e) v[e] = canon_lo(src[G::j_p1(lane, e)], qhalf, bad);
     uint64_t sum = 0;
     uint32_t mx = 0;
 #pragma unroll
@@ -146,7 +186,9 @@ __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict
       mx = a1 > mx ? a1 : mx;
     }
     l1 = (double)wave_sum_u64(sum);
-    linf = (double)wave_max_u32(mx);
+    const uint32_t wmx = wave_max_u32(mx);
+    linf = (double)wmx;
+    fault = fault || __any(bad != 0) || wmx > qhalf;
     if (want_sq) {
       uint64_t sq = 0;
 #pragma unroll
@@ -157,6 +199,9 @@ __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict
       }
       sumsq = wave_sum_u64(sq);
     }
+  } else {
+#pragma unroll
+    for (int e = 0; e < G::E; ++e) v[e] = (int32_t)src[G::j_p1(lane, e)];
   }
 #pragma unroll
   for (int e = 0; e < G::E; ++e) x[e] = lift(v[e], pc);
@@ -187,12 +232,14 @@ __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict
 // ---- challenge products as signed rotations (ShiftGeo, rzk_core.h): shared by shift_row_kernel and the
 // shift terms of row_kernel ---------------------------------------------------------------------------------
 template <int LOGN>
-__device__ __forceinline__ void load_pairs(int32_t* v, const int64_t* __restrict__ src, int lane) {
+__device__ __forceinline__ void load_pairs(int32_t* v, const int64_t* __restrict__ src, int lane, uint32_t qhalf,
+                                           uint32_t& bad, uint32_t& mx) {
   using S = ShiftGeo<LOGN>;
   const int4* __restrict__ p = reinterpret_cast<const int4*>(src);
 #pragma unroll
   for (int g = 0; g < S::G; ++g) {
-    const int4 t = p[g * 64 + lane];   // coefficients g*128 + 2*lane, +1 (low words of two int64)
+    const int4 t = p[g * 64 + lane];   // coefficients g*128 + 2*lane, +1 (two int64)
+    canon_pair(t, qhalf, bad, mx);
     v[2 * g] = t.x;
     v[2 * g + 1] = t.z;
   }
@@ -232,7 +279,7 @@ __device__ __forceinline__ void shift_scan(int64_t* acc, const int32_t* a, int l
 template <int LOGN, bool PAIR, bool TO_MEM>
 __device__ __forceinline__ void shift_product(uint32_t* res, bool fresh, bool minus, const int32_t* a,
                                               const int64_t* __restrict__ pv, int lane, int32_t* ext,
-                                              const DevTables& T) {
+                                              const DevTables& T, bool& fault) {
   using S = ShiftGeo<LOGN, PAIR>;
   constexpr int E = S::E;
   constexpr int H = RZK_SHIFT_H < E ? RZK_SHIFT_H : E;   // outputs per scan; chunk c covers registers c*H .. c*H+H-1
@@ -243,13 +290,15 @@ __device__ __forceinline__ void shift_product(uint32_t* res, bool fresh, bool mi
   for (int pass = 0; pass < npass; ++pass) {
     {
       int32_t v[E];
+      uint32_t vbad = 0, vmx = 0;
       if (PAIR) {
-        load_pairs<LOGN>(v, pv, lane);
+        load_pairs<LOGN>(v, pv, lane, T.crt.qhalf, vbad, vmx);
       } else {
 #pragma unroll
-        for (int i = 0; i < E; ++i) v[i] = (int32_t)pv[S::j(lane, i)];
+        for (int i = 0; i < E; ++i) v[i] = canon_lo_mx(pv[S::j(lane, i)], T.crt.qhalf, vbad, vmx);
       }
       if (pass == 0) {
+        fault = fault || canon_fail(vbad, vmx, T.crt.qhalf);
         uint64_t suma = 0;
         uint32_t maxv = 0;
 #pragma unroll
@@ -298,7 +347,7 @@ __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const 
                                             uint32_t bo, int lane, uint32_t* lds, const uint32_t* __restrict__ twf,
                                             const PrimeConsts& pc, int pi, const uint32_t* __restrict__ key_ntt,
                                             const double* __restrict__ key_inf, bool first, double& bound,
-                                            uint8_t* __restrict__ flags) {
+                                            uint8_t* __restrict__ flags, uint32_t qhalf) {
   using G = Geo<LOGN>;
   constexpr int E = G::E;
   constexpr int N = G::N;
@@ -308,8 +357,9 @@ __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const 
   uint32_t x[E];
   double l1b = 0, infb = 0;
   uint64_t sumsq = 0;
+  bool fault = false;
   const bool chk = first && (tm.kind & (TERM_CHECK | TERM_CHECK2));
-  load_lift<LOGN>(x, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), ln, pc, first, l1b, infb, chk, sumsq);
+  load_lift<LOGN>(x, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), ln, pc, first, l1b, infb, chk, sumsq, qhalf, fault);
   if (chk && sumsq >= ops.norm_limit && lane == 0) fail_check(flags + bo, ops.pad != 0, (tm.kind & TERM_CHECK2) != 0);
   wave_fwd<LOGN>(x, ln, lds, twf, pc);
   if (HAS_VEC && (tm.kind & TERM_KIND_MASK) == TERM_VEC) {
@@ -319,7 +369,7 @@ __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const 
     for (int c = 0; c < E; ++c) xb[c] = csub(mont_lazy(x[c], pc.ninv_r2, pc.p, pc.npinv), pc.p);
     double l1a = 0, infa = 0;
     uint64_t unused_sq = 0;
-    load_lift<LOGN>(x, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), ln, pc, first, l1a, infa, false, unused_sq);
+    load_lift<LOGN>(x, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), ln, pc, first, l1a, infa, false, unused_sq, qhalf, fault);
     wave_fwd<LOGN>(x, ln, lds, twf, pc);
     if (first) {
       const double u = l1a * infb, v = infa * l1b;
@@ -355,6 +405,7 @@ __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const 
       }
     }
   }
+  if (fault) input_fault(ops, flags, bo, lane);
 }
 
 // inverse transform of the prime-`pi` accumulator and fold into the Garner state: word A in LDS, word B
@@ -408,6 +459,7 @@ __device__ __forceinline__ void row_epilogue(const Program* __restrict__ prog, c
   constexpr int CH = RZK_EPI_CHUNK < E ? RZK_EPI_CHUNK : E;
   const uint32_t q = T.crt.q;
   uint64_t add_sq[4] = {0, 0, 0, 0};   // per-lane partial sums of squares of checked additions (slot = add index)
+  uint32_t in_bad = 0, in_mx = 0;      // canonical-input test of the additions' coefficients
 #pragma unroll
   for (int e0 = 0; e0 < E; e0 += CH) {
     uint32_t u[CH];
@@ -428,7 +480,7 @@ __device__ __forceinline__ void row_epilogue(const Program* __restrict__ prog, c
       const int64_t* __restrict__ src = operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, N);
       int32_t av[CH];
 #pragma unroll
-      for (int i = 0; i < CH; ++i) av[i] = (int32_t)src[G::j_p1(lane, e0 + i)];
+      for (int i = 0; i < CH; ++i) av[i] = canon_lo_mx(src[G::j_p1(lane, e0 + i)], T.crt.qhalf, in_bad, in_mx);
       if (ad.op & (ADD_CHECK | ADD_CHECK2)) {
         uint64_t sq = 0;
 #pragma unroll
@@ -459,6 +511,7 @@ __device__ __forceinline__ void row_epilogue(const Program* __restrict__ prog, c
   if (row.mode != MODE_STORE) {
     if (__any(nz) && lane == 0) flags[bo] = 0;
   }
+  if (row.nadds && canon_fail(in_bad, in_mx, T.crt.qhalf)) input_fault(ops, flags, bo, lane);
   if (ops.norm_limit) {
     // checked additions: the host marks them only among the first four additions of a row
 #pragma unroll 1
@@ -525,9 +578,13 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
         const int64_t* __restrict__ pa = operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N);
         const int64_t* __restrict__ pv = operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N);
         int32_t a[E];
+        uint32_t abad = 0, amx = 0;
 #pragma unroll
-        for (int e = 0; e < E; ++e) a[e] = (int32_t)pa[G::j_p1(lane, e)];
-        shift_product<LOGN, false, true>(st_sh, t == 0, tm.sign < 0, a, pv, lane, reinterpret_cast<int32_t*>(lds), T);
+        for (int e = 0; e < E; ++e) a[e] = canon_lo_mx(pa[G::j_p1(lane, e)], T.crt.qhalf, abad, amx);
+        bool fault = canon_fail(abad, amx, T.crt.qhalf);
+        shift_product<LOGN, false, true>(st_sh, t == 0, tm.sign < 0, a, pv, lane, reinterpret_cast<int32_t*>(lds), T,
+                                         fault);
+        if (fault) input_fault(ops, flags, bo, lane);
       }
       wave_sync();   // the image is dead: the slab and state words may be overwritten
     }
@@ -547,7 +604,7 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
 #pragma unroll 1
         for (uint32_t t = 0; t < row.nterms; ++t)
           term_direct<LOGN, HAS_VEC, HAS_SHIFT || RZK_ROW_OPAQUE>(acc, prog->terms[row.term0 + t], ops, b, bo, lane, lds, twf, pc, pi, key_ntt,
-                                     key_inf, first, bound, flags);
+                                     key_inf, first, bound, flags, T.crt.qhalf);
         if (first) np = primes_for(bound, T);
         inverse_and_fold<LOGN, HAS_SHIFT || RZK_ROW_OPAQUE>(pi, np, acc, lane, lds, twf + kTableLen, pc, st_lds, st_glb, T);
       }
@@ -598,37 +655,24 @@ shift_row_kernel(const Program* __restrict__ prog, const Operands ops, const Dev
     uint32_t res[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) res[i] = 0;
-    // the first addition is fetched ahead of the rotations so that its latency is hidden behind them
-    int32_t av0[E];
-    AddTerm ad0{};
-    if (row.nadds > 0) {
-      ad0 = prog->adds[row.add0];
-      load_pairs<LOGN>(av0, operand_ptr(ops, ad0.op & ADD_OP_MASK, ad0.off, b, bo, N), lane);
-    }
+    const uint32_t qhalf = T.crt.qhalf;
+    uint32_t in_bad = 0, in_mx = 0;   // canonical-input test of everything loaded outside shift_product
+    bool fault = false;
 
 #pragma unroll 1
     for (uint32_t t = 0; t < row.nterms; ++t) {
       const Term tm = prog->terms[row.term0 + t];
       int32_t a[E];
-      load_pairs<LOGN>(a, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), lane);
+      load_pairs<LOGN>(a, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), lane, qhalf, in_bad, in_mx);
       shift_product<LOGN, true, false>(res, false, tm.sign < 0, a, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane,
-                                       slab, T);
+                                       slab, T, fault);
     }
 
-    if (row.nadds > 0) {
-      if (ad0.sign >= 0) {
-#pragma unroll
-        for (int i = 0; i < E; ++i) res[i] = addq(res[i], zq_from_centered(av0[i], q), q);
-      } else {
-#pragma unroll
-        for (int i = 0; i < E; ++i) res[i] = subq(res[i], zq_from_centered(av0[i], q), q);
-      }
-    }
 #pragma unroll 1
-    for (uint32_t ai = 1; ai < row.nadds; ++ai) {
+    for (uint32_t ai = 0; ai < row.nadds; ++ai) {
       const AddTerm ad = prog->adds[row.add0 + ai];
       int32_t av[E];
-      load_pairs<LOGN>(av, operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, N), lane);
+      load_pairs<LOGN>(av, operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, N), lane, qhalf, in_bad, in_mx);
       if (ad.sign >= 0) {
 #pragma unroll
         for (int i = 0; i < E; ++i) res[i] = addq(res[i], zq_from_centered(av[i], q), q);
@@ -637,6 +681,7 @@ shift_row_kernel(const Program* __restrict__ prog, const Operands ops, const Dev
         for (int i = 0; i < E; ++i) res[i] = subq(res[i], zq_from_centered(av[i], q), q);
       }
     }
+    if (fault || canon_fail(in_bad, in_mx, qhalf)) input_fault(ops, flags, bo, lane);
     if (row.mode == MODE_STORE) {
       int4* __restrict__ dst = reinterpret_cast<int4*>(const_cast<int64_t*>(operand_ptr(ops, row.out_op, row.out_off, b, bo, N)));
 #pragma unroll
@@ -715,8 +760,11 @@ row_group_kernel(const Program* __restrict__ prog, const Operands ops, const uin
           const bool chk = first && (tm0.kind & TERM_CHECK);
           int ln = lane;
           if (RZK_GROUP_OPAQUE) asm volatile("" : "+v"(ln));   // no hoisting of lane-dependent addresses (register budget)
-          load_lift<LOGN>(x, operand_ptr(ops, tm0.b_op, tm0.b_off, b, bo, N), ln, pc, first, l1, linf, chk, sumsq);
+          bool fault = false;
+          load_lift<LOGN>(x, operand_ptr(ops, tm0.b_op, tm0.b_off, b, bo, N), ln, pc, first, l1, linf, chk, sumsq,
+                          T.crt.qhalf, fault);
           if (chk && sumsq >= ops.norm_limit && lane == 0) flags[bo] = 0;
+          if (fault) input_fault(ops, flags, bo, lane);
           wave_fwd<LOGN>(x, ln, lds, twf, pc);
 #pragma unroll
           for (int g = 0; g < GM; ++g) {
@@ -812,9 +860,11 @@ row_block_kernel(const Program* __restrict__ prog, const BlockPlan* __restrict__
         double l1 = 0, linf = 0;
         uint64_t sumsq = 0;
         const bool chk = first && plan->slot_check[gs] && ops.norm_limit;
+        bool fault = false;
         load_lift<LOGN>(x, operand_ptr(ops, plan->slot_op[gs], plan->slot_off[gs], b, bo, N), lane, pc, first, l1, linf,
-                        chk, sumsq);
+                        chk, sumsq, T.crt.qhalf, fault);
         if (chk && sumsq >= ops.norm_limit && lane == 0) flags[bo] = 0;
+        if (fault) input_fault(ops, flags, bo, lane);
         if (first && lane == 0) norm1[s] = l1;
         wave_fwd<LOGN>(x, lane, lds, twf, pc);
         uint32_t* dst = staged + s * N + lane;
@@ -897,8 +947,10 @@ fwd_slots_kernel(const SlotTable* __restrict__ slots, const Operands ops, const 
     const uint32_t bo = ops.group > 1 ? b / ops.group : b;
     const int64_t* __restrict__ src = operand_ptr(ops, slots->op[s], slots->off[s], b, bo, N);
     int32_t v[E];
+    uint32_t in_bad = 0, in_mx = 0;
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = (int32_t)src[G::j_p1(lane, e)];
+    for (int e = 0; e < E; ++e) v[e] = canon_lo_mx(src[G::j_p1(lane, e)], T.crt.qhalf, in_bad, in_mx);
+    if (canon_fail(in_bad, in_mx, T.crt.qhalf)) input_fault(ops, flags, bo, lane);
     uint64_t sum = 0, sq = 0;
     uint32_t mx = 0;
 #pragma unroll
@@ -1033,7 +1085,8 @@ row_slots_kernel(const Program* __restrict__ prog, const SlotTable* __restrict__
           for (uint32_t t = 0; t < row.nterms; ++t) {
             Term tm = prog->terms[row.term0 + t];
             tm.kind &= TERM_KIND_MASK;   // norm predicate already evaluated by the forward pass
-            term_direct<LOGN, true>(acc, tm, ops, b, bo, lane, lds, twf, pc, pi, key_ntt, key_inf, false, unused, flags);
+            term_direct<LOGN, true>(acc, tm, ops, b, bo, lane, lds, twf, pc, pi, key_ntt, key_inf, false, unused, flags,
+                                    T.crt.qhalf);
           }
         }
         inverse_and_fold<LOGN>(pi, np, acc, lane, lds, twf + kTableLen, pc, st_lds, st_glb, T);
@@ -1155,20 +1208,25 @@ ntt_inv_kernel(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint
 // =============================================================================================
 __global__ void __launch_bounds__(256)
 addsub_kernel(const int64_t* a, const int64_t* b, int64_t* out, uint64_t n2, int sub,
-              const DevTables* __restrict__ Tp) {
+              const DevTables* __restrict__ Tp, uint32_t* __restrict__ bad_word) {
   // two coefficients (16 bytes) per thread and step; out may alias a or b (in-place add/sub)
   const DevTables& T = *Tp;
   const longlong2* a2 = reinterpret_cast<const longlong2*>(a);
   const longlong2* b2 = reinterpret_cast<const longlong2*>(b);
   longlong2* o2 = reinterpret_cast<longlong2*>(out);
+  const uint64_t h = T.crt.qhalf;
+  bool fault = false;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
        i += (uint64_t)gridDim.x * blockDim.x) {
     const longlong2 x = a2[i], y = b2[i];
+    fault = fault || (uint64_t)x.x + h > 2 * h || (uint64_t)x.y + h > 2 * h || (uint64_t)y.x + h > 2 * h ||
+            (uint64_t)y.y + h > 2 * h;   // canonical inputs only (see canon_lo)
     longlong2 r;
     r.x = center_rounds<1>(sub ? x.x - y.x : x.x + y.x, T.crt);
     r.y = center_rounds<1>(sub ? x.y - y.y : x.y + y.y, T.crt);
     o2[i] = r;
   }
+  if (fault && bad_word) *bad_word = 1u;
 }
 
 // One wavefront per proof: all `rows` polynomials must satisfy sum c^2 < limit (= (bound+1)^2),
@@ -1177,7 +1235,8 @@ addsub_kernel(const int64_t* a, const int64_t* b, int64_t* out, uint64_t n2, int
 template <int LOGN>
 __global__ void __launch_bounds__(256)
 norm_kernel(const int64_t* __restrict__ v, uint32_t rows, uint64_t limit_hi, uint64_t limit_lo,
-            uint8_t* __restrict__ ok, uint64_t B, int and_mode, int shift) {
+            uint8_t* __restrict__ ok, uint64_t B, int and_mode, int shift, uint32_t qhalf,
+            uint32_t* __restrict__ bad_word) {
   using G = Geo<LOGN>;
   constexpr int E = G::E;
   constexpr int N = G::N;
@@ -1188,12 +1247,12 @@ norm_kernel(const int64_t* __restrict__ v, uint32_t rows, uint64_t limit_hi, uin
     for (uint32_t r = 0; r < rows; ++r) {
       const int64_t* __restrict__ p = v + (b * rows + r) * N;
       uint64_t slo = 0, shi = 0;
-      int huge = 0;   // |c| >= 2^32 already exceeds every admissible bound (bound < 2^32)
+      int huge = 0;   // a coefficient outside the centred range: not a ZqI64 value, the predicate fails
 #pragma unroll
       for (int e = 0; e < E; ++e) {
         const int64_t c = p[G::j_p1(lane, e)];
         const uint64_t a = c < 0 ? 0ull - (uint64_t)c : (uint64_t)c;
-        huge |= (a >> 32) != 0;
+        huge |= a > (uint64_t)qhalf;
         const uint64_t al = a & 0xffffffffu;
         const uint64_t ll = al * al;
         slo += ll & 0xffffffffu;
@@ -1207,7 +1266,9 @@ norm_kernel(const int64_t* __restrict__ v, uint32_t rows, uint64_t limit_hi, uin
       const uint64_t tot_lo = (mid << 32) | t_lo32;
       const uint64_t tot_hi = mid >> 32;
       const int lt = (tot_hi < limit_hi) || (tot_hi == limit_hi && tot_lo < limit_lo);
-      good &= lt && !__any(huge);
+      const int any_huge = __any(huge);
+      good &= lt && !any_huge;
+      if (any_huge && bad_word && lane == 0) *bad_word = 1u;
     }
     if (lane == 0) {
       if (and_mode == 0)
@@ -1223,22 +1284,30 @@ norm_kernel(const int64_t* __restrict__ v, uint32_t rows, uint64_t limit_hi, uin
 template <int LOGN>
 __global__ void __launch_bounds__(256)
 eq_kernel(const int64_t* __restrict__ a, const int64_t* __restrict__ b, uint32_t rows,
-          uint8_t* __restrict__ eq, uint64_t B) {
+          uint8_t* __restrict__ eq, uint64_t B, uint32_t qhalf, uint32_t* __restrict__ bad_word) {
   using G = Geo<LOGN>;
   constexpr int E = G::E;
   constexpr int N = G::N;
   const int lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (uint64_t p = (uint64_t)blockIdx.x * 4 + wave; p < B; p += (uint64_t)gridDim.x * 4) {
-    int ne = 0;
+    int ne = 0, bad = 0;
     for (uint32_t r = 0; r < rows; ++r) {
       const int64_t* __restrict__ pa = a + (p * rows + r) * N;
       const int64_t* __restrict__ pb = b + (p * rows + r) * N;
 #pragma unroll
-      for (int e = 0; e < E; ++e) ne |= (pa[G::j_p1(lane, e)] != pb[G::j_p1(lane, e)]);
+      for (int e = 0; e < E; ++e) {
+        const int64_t x = pa[G::j_p1(lane, e)], y = pb[G::j_p1(lane, e)];
+        ne |= (x != y);
+        // equality of canonical forms (derived PartialEq): anything else is not a ZqI64 value
+        bad |= ((uint64_t)x + qhalf > 2ull * qhalf) | ((uint64_t)y + qhalf > 2ull * qhalf);
+      }
     }
-    const int any_ne = __any(ne);
-    if (lane == 0) eq[p] = (uint8_t)(any_ne ? 0 : 1);
+    const int any_ne = __any(ne), any_bad = __any(bad);
+    if (lane == 0) {
+      eq[p] = (uint8_t)((any_ne || any_bad) ? 0 : 1);
+      if (any_bad && bad_word) *bad_word = 1u;
+    }
   }
 }
 
@@ -1271,6 +1340,8 @@ row_kernel_small(const Program* __restrict__ prog, const Operands ops, const uin
     uint64_t pos[EMAX], neg[EMAX];
 #pragma unroll
     for (int e = 0; e < EMAX; ++e) pos[e] = neg[e] = 0;
+    const uint32_t qhalf = T.crt.qhalf;
+    uint32_t in_bad = 0, in_mx = 0;   // canonical-input test of every coefficient this row loads
 
     for (uint32_t t = 0; t < row.nterms; ++t) {
       const Term tm = prog->terms[row.term0 + t];
@@ -1278,14 +1349,14 @@ row_kernel_small(const Program* __restrict__ prog, const Operands ops, const uin
       if ((tm.kind & TERM_KIND_MASK) == TERM_KEY) {
         const uint32_t* __restrict__ km = key_mont + (size_t)tm.a_off * N;
         for (uint32_t i = lane; i < N; i += 64) {
-          la[i] = zq_from_centered((int32_t)pb[i], q);
+          la[i] = zq_from_centered(canon_lo_mx(pb[i], qhalf, in_bad, in_mx), q);
           lb[i] = km[i];
         }
       } else {
         const int64_t* __restrict__ pa = operand_ptr(ops, tm.a_op, tm.a_off, b, bo, (int)N);
         for (uint32_t i = lane; i < N; i += 64) {
-          la[i] = zq_from_centered((int32_t)pa[i], q);
-          lb[i] = montq_u(zq_from_centered((int32_t)pb[i], q), r2q, T.crt);
+          la[i] = zq_from_centered(canon_lo_mx(pa[i], qhalf, in_bad, in_mx), q);
+          lb[i] = montq_u(zq_from_centered(canon_lo_mx(pb[i], qhalf, in_bad, in_mx), q), r2q, T.crt);
         }
       }
       wave_sync();
@@ -1312,7 +1383,8 @@ row_kernel_small(const Program* __restrict__ prog, const Operands ops, const uin
         uint32_t u = subq((uint32_t)(pos[e] % q), (uint32_t)(neg[e] % q), q);
         for (uint32_t a = 0; a < row.nadds; ++a) {
           const AddTerm ad = prog->adds[row.add0 + a];
-          const uint32_t v = zq_from_centered((int32_t)operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, (int)N)[tt], q);
+          const uint32_t v = zq_from_centered(
+              canon_lo_mx(operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, (int)N)[tt], qhalf, in_bad, in_mx), q);
           u = ad.sign >= 0 ? addq(u, v, q) : subq(u, v, q);
         }
         if (row.mode == MODE_STORE)
@@ -1324,6 +1396,7 @@ row_kernel_small(const Program* __restrict__ prog, const Operands ops, const uin
     if (row.mode != MODE_STORE) {
       if (__any(nz) && lane == 0) flags[bo] = 0;
     }
+    if (canon_fail(in_bad, in_mx, qhalf)) input_fault(ops, flags, bo, (int)lane);
   }
 }
 
@@ -1339,7 +1412,8 @@ key_mont_kernel(const int64_t* __restrict__ key, uint32_t* __restrict__ key_mont
 // norm / equality for any N (used below N = 512): one wavefront per proof
 __global__ void __launch_bounds__(256)
 norm_kernel_small(const int64_t* __restrict__ v, uint32_t rows, uint64_t limit_hi, uint64_t limit_lo,
-                  uint8_t* __restrict__ ok, uint64_t B, int and_mode, int shift, uint32_t N) {
+                  uint8_t* __restrict__ ok, uint64_t B, int and_mode, int shift, uint32_t N, uint32_t qhalf,
+                  uint32_t* __restrict__ bad_word) {
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (uint64_t b = (uint64_t)blockIdx.x * 4 + wave; b < B; b += (uint64_t)gridDim.x * 4) {
@@ -1351,7 +1425,7 @@ norm_kernel_small(const int64_t* __restrict__ v, uint32_t rows, uint64_t limit_h
       for (uint32_t i = lane; i < N; i += 64) {
         const int64_t c = p[i];
         const uint64_t a = c < 0 ? 0ull - (uint64_t)c : (uint64_t)c;
-        huge |= (a >> 32) != 0;
+        huge |= a > (uint64_t)qhalf;
         const uint64_t al = a & 0xffffffffu;
         const uint64_t ll = al * al;
         slo += ll & 0xffffffffu;
@@ -1363,7 +1437,9 @@ norm_kernel_small(const int64_t* __restrict__ v, uint32_t rows, uint64_t limit_h
       const uint64_t tot_lo = (mid << 32) | (slo & 0xffffffffu);
       const uint64_t tot_hi = mid >> 32;
       const int lt = (tot_hi < limit_hi) || (tot_hi == limit_hi && tot_lo < limit_lo);
-      good &= lt && !__any(huge);
+      const int any_huge = __any(huge);
+      good &= lt && !any_huge;
+      if (any_huge && bad_word && lane == 0) *bad_word = 1u;
     }
     if (lane == 0) {
       if (and_mode == 0)
@@ -1378,15 +1454,22 @@ norm_kernel_small(const int64_t* __restrict__ v, uint32_t rows, uint64_t limit_h
 
 __global__ void __launch_bounds__(256)
 eq_kernel_small(const int64_t* __restrict__ a, const int64_t* __restrict__ b, uint32_t rows,
-                uint8_t* __restrict__ eq, uint64_t B, uint32_t N) {
+                uint8_t* __restrict__ eq, uint64_t B, uint32_t N, uint32_t qhalf, uint32_t* __restrict__ bad_word) {
   const uint32_t lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (uint64_t p = (uint64_t)blockIdx.x * 4 + wave; p < B; p += (uint64_t)gridDim.x * 4) {
-    int ne = 0;
+    int ne = 0, bad = 0;
     const uint64_t n = (uint64_t)rows * N;
-    for (uint64_t i = lane; i < n; i += 64) ne |= (a[p * n + i] != b[p * n + i]);
-    const int any_ne = __any(ne);
-    if (lane == 0) eq[p] = (uint8_t)(any_ne ? 0 : 1);
+    for (uint64_t i = lane; i < n; i += 64) {
+      const int64_t x = a[p * n + i], y = b[p * n + i];
+      ne |= (x != y);
+      bad |= ((uint64_t)x + qhalf > 2ull * qhalf) | ((uint64_t)y + qhalf > 2ull * qhalf);
+    }
+    const int any_ne = __any(ne), any_bad = __any(bad);
+    if (lane == 0) {
+      eq[p] = (uint8_t)((any_ne || any_bad) ? 0 : 1);
+      if (any_bad && bad_word) *bad_word = 1u;
+    }
   }
 }
 
@@ -1600,12 +1683,13 @@ static int launch_blocks_t(const LaunchCfg& cfg, const Program* d_prog, const Bl
   using G = Geo<LOGN>;
   const size_t lds = ((size_t)kBlockMaxSlots * G::N + (size_t)kBlockWaves * G::LDS_WORDS) * sizeof(uint32_t) +
                      kBlockMaxSlots * sizeof(double);
-  static bool attr_set = false;   // > 64 KiB of dynamic LDS needs an explicit opt-in, once per kernel
-  if (!attr_set) {
+  // > 64 KiB of dynamic LDS needs an explicit opt-in.  The attribute is kept per device and contexts may live on
+  // several devices / host threads, so it is set (idempotently, a host-side call of ~1 us) before every launch
+  // rather than behind a process-wide "done" flag.
+  {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&row_block_kernel<LOGN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
   }
   uint32_t grid = ntasks < (uint32_t)cfg.num_cus * 2 ? ntasks : (uint32_t)cfg.num_cus * 2;   // scratch: num_cus * 2 lines
   hipLaunchKernelGGL((row_block_kernel<LOGN>), dim3(grid), dim3(64 * kBlockWaves), lds, (hipStream_t)cfg.stream, d_prog,
@@ -1775,34 +1859,35 @@ int launch_canonicalize(const LaunchCfg& cfg, const int64_t* in, int64_t* out, u
 }
 
 int launch_addsub(const LaunchCfg& cfg, bool sub, const int64_t* a, const int64_t* b, int64_t* out,
-                  uint64_t ncoef, const DevTables* T) {
+                  uint64_t ncoef, const DevTables* T, uint32_t* bad_word) {
   if (ncoef == 0) return 0;
   const uint64_t n2 = ncoef / 2;   // ncoef is a multiple of N >= 512
   uint64_t blocks = (n2 + 255) / 256;
   const uint64_t cap = (uint64_t)cfg.num_cus * 8;
   if (blocks > cap) blocks = cap;
   hipLaunchKernelGGL(addsub_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)cfg.stream, a, b,
-                     out, n2, sub ? 1 : 0, T);
+                     out, n2, sub ? 1 : 0, T, bad_word);
   RZK_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_norm(int logn, const LaunchCfg& cfg, const int64_t* v, uint32_t rows, uint64_t limit_hi,
-                uint64_t limit_lo, uint8_t* ok, uint64_t B, int and_mode, int shift) {
+                uint64_t limit_lo, uint8_t* ok, uint64_t B, int and_mode, int shift, uint32_t qhalf,
+                uint32_t* bad_word) {
   if (B == 0) return 0;
   const unsigned grid = grid_for(B, cfg.num_cus);
   switch (logn) {
     case 9:
       hipLaunchKernelGGL(norm_kernel<9>, dim3(grid), dim3(256), 0, (hipStream_t)cfg.stream, v, rows,
-                         limit_hi, limit_lo, ok, B, and_mode, shift);
+                         limit_hi, limit_lo, ok, B, and_mode, shift, qhalf, bad_word);
       break;
     case 10:
       hipLaunchKernelGGL(norm_kernel<10>, dim3(grid), dim3(256), 0, (hipStream_t)cfg.stream, v, rows,
-                         limit_hi, limit_lo, ok, B, and_mode, shift);
+                         limit_hi, limit_lo, ok, B, and_mode, shift, qhalf, bad_word);
       break;
     case 11:
       hipLaunchKernelGGL(norm_kernel<11>, dim3(grid), dim3(256), 0, (hipStream_t)cfg.stream, v, rows,
-                         limit_hi, limit_lo, ok, B, and_mode, shift);
+                         limit_hi, limit_lo, ok, B, and_mode, shift, qhalf, bad_word);
       break;
     default: return -1;
   }
@@ -1811,18 +1896,21 @@ int launch_norm(int logn, const LaunchCfg& cfg, const int64_t* v, uint32_t rows,
 }
 
 int launch_eq(int logn, const LaunchCfg& cfg, const int64_t* a, const int64_t* b, uint32_t rows,
-              uint8_t* eq, uint64_t B) {
+              uint8_t* eq, uint64_t B, uint32_t qhalf, uint32_t* bad_word) {
   if (B == 0) return 0;
   const unsigned grid = grid_for(B, cfg.num_cus);
   switch (logn) {
     case 9:
-      hipLaunchKernelGGL(eq_kernel<9>, dim3(grid), dim3(256), 0, (hipStream_t)cfg.stream, a, b, rows, eq, B);
+      hipLaunchKernelGGL(eq_kernel<9>, dim3(grid), dim3(256), 0, (hipStream_t)cfg.stream, a, b, rows, eq, B, qhalf,
+                         bad_word);
       break;
     case 10:
-      hipLaunchKernelGGL(eq_kernel<10>, dim3(grid), dim3(256), 0, (hipStream_t)cfg.stream, a, b, rows, eq, B);
+      hipLaunchKernelGGL(eq_kernel<10>, dim3(grid), dim3(256), 0, (hipStream_t)cfg.stream, a, b, rows, eq, B, qhalf,
+                         bad_word);
       break;
     case 11:
-      hipLaunchKernelGGL(eq_kernel<11>, dim3(grid), dim3(256), 0, (hipStream_t)cfg.stream, a, b, rows, eq, B);
+      hipLaunchKernelGGL(eq_kernel<11>, dim3(grid), dim3(256), 0, (hipStream_t)cfg.stream, a, b, rows, eq, B, qhalf,
+                         bad_word);
       break;
     default: return -1;
   }
@@ -1856,19 +1944,20 @@ int launch_key_mont(const LaunchCfg& cfg, const int64_t* d_key, uint32_t* d_key_
 }
 
 int launch_norm_small(uint32_t N, const LaunchCfg& cfg, const int64_t* v, uint32_t rows, uint64_t limit_hi,
-                      uint64_t limit_lo, uint8_t* ok, uint64_t B, int and_mode, int shift) {
+                      uint64_t limit_lo, uint8_t* ok, uint64_t B, int and_mode, int shift, uint32_t qhalf,
+                      uint32_t* bad_word) {
   if (B == 0) return 0;
   hipLaunchKernelGGL(norm_kernel_small, dim3(grid_for(B, cfg.num_cus)), dim3(256), 0, (hipStream_t)cfg.stream, v,
-                     rows, limit_hi, limit_lo, ok, B, and_mode, shift, N);
+                     rows, limit_hi, limit_lo, ok, B, and_mode, shift, N, qhalf, bad_word);
   RZK_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_eq_small(uint32_t N, const LaunchCfg& cfg, const int64_t* a, const int64_t* b, uint32_t rows,
-                    uint8_t* eq, uint64_t B) {
+                    uint8_t* eq, uint64_t B, uint32_t qhalf, uint32_t* bad_word) {
   if (B == 0) return 0;
   hipLaunchKernelGGL(eq_kernel_small, dim3(grid_for(B, cfg.num_cus)), dim3(256), 0, (hipStream_t)cfg.stream, a, b,
-                     rows, eq, B, N);
+                     rows, eq, B, N, qhalf, bad_word);
   RZK_LAUNCH_CHECK();
   return 0;
 }

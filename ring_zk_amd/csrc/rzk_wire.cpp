@@ -67,9 +67,10 @@ int rzk_wire_mat_encode(const int64_t* slab, uint32_t rows, uint32_t cols, uint3
   return RZK_OK;
 }
 
-int rzk_wire_mat_decode(const uint8_t* in, size_t len, uint32_t N, uint32_t coef_bytes, uint32_t* rows_out,
+int rzk_wire_mat_decode(const uint8_t* in, size_t len, uint32_t N, uint32_t coef_bytes, int64_t q, uint32_t* rows_out,
                         uint32_t* cols_out, int64_t* slab, size_t slab_polys, size_t* consumed) {
-  if (!in || (coef_bytes != 4 && coef_bytes != 8) || !rows_out || !cols_out) return RZK_E_ARG;
+  if (!in || (coef_bytes != 4 && coef_bytes != 8) || !rows_out || !cols_out || q < 0) return RZK_E_ARG;
+  const int64_t half = q > 0 ? (q - 1) / 2 : 0;   // q > 0: coefficients must be centred residues mod q
   size_t pos = 0;
   auto need = [&](size_t n) { return len - pos >= n; };
   if (!need(8)) return RZK_E_ARG;
@@ -89,16 +90,18 @@ int rzk_wire_mat_decode(const uint8_t* in, size_t len, uint32_t N, uint32_t coef
       const uint64_t plen = get_u64(in + pos);
       pos += 8;
       if (plen > N || !need(plen * coef_bytes)) return RZK_E_ARG;   // degree >= N cannot be in Z[X]/(X^N+1)
-      if (slab) {
-        if (poly_index >= slab_polys) return RZK_E_ARG;
-        int64_t* poly = slab + poly_index * N;
-        for (uint64_t i = 0; i < plen; ++i) {
-          uint64_t v = 0;
-          for (uint32_t b = 0; b < coef_bytes; ++b) v |= (uint64_t)in[pos + i * coef_bytes + b] << (8 * b);
-          poly[i] = coef_bytes == 4 ? (int64_t)(int32_t)(uint32_t)v : (int64_t)v;
-        }
-        std::memset(poly + plen, 0, (size_t)(N - plen) * sizeof(int64_t));   // trimmed -> dense
+      if (slab && poly_index >= slab_polys) return RZK_E_ARG;
+      int64_t* poly = slab ? slab + poly_index * N : nullptr;
+      for (uint64_t i = 0; i < plen; ++i) {
+        uint64_t v = 0;
+        for (uint32_t b = 0; b < coef_bytes; ++b) v |= (uint64_t)in[pos + i * coef_bytes + b] << (8 * b);
+        const int64_t cv = coef_bytes == 4 ? (int64_t)(int32_t)(uint32_t)v : (int64_t)v;
+        // a ZqI64 holds the centred representative (src/params.rs:122-127): anything else on the wire is not a
+        // ring element and must not reach the verifier kernels as its low word
+        if (q > 0 && (cv > half || cv < -half)) return RZK_E_ARG;
+        if (poly) poly[i] = cv;
       }
+      if (poly) std::memset(poly + plen, 0, (size_t)(N - plen) * sizeof(int64_t));   // trimmed -> dense
       pos += plen * coef_bytes;
       ++poly_index;
     }

@@ -33,17 +33,18 @@ def mat_encode(slab: np.ndarray, coef_bytes: int = 8) -> bytes:
     return out[:written.value].tobytes()
 
 
-def mat_decode(data: bytes, N: int, coef_bytes: int = 8) -> Tuple[np.ndarray, int]:
-    """bincode bytes -> (int64 [rows][cols][N] slab, bytes consumed).  Raises ValueError on malformed input."""
+def mat_decode(data: bytes, N: int, coef_bytes: int = 8, q: int = 0) -> Tuple[np.ndarray, int]:
+    """bincode bytes -> (int64 [rows][cols][N] slab, bytes consumed).  Raises ValueError on malformed input and,
+    with q > 0 (a message over ZqI64<q>), on any coefficient outside the centred range mod q."""
     buf = np.frombuffer(data, dtype=np.uint8)
     L = _lib.lib()
     rows, cols, used = C.c_uint32(0), C.c_uint32(0), C.c_size_t(0)
     ptr = C.c_void_p(buf.ctypes.data) if buf.size else C.c_void_p(0)
-    rc = L.rzk_wire_mat_decode(ptr, buf.size, N, coef_bytes, C.byref(rows), C.byref(cols), None, 0, C.byref(used))
+    rc = L.rzk_wire_mat_decode(ptr, buf.size, N, coef_bytes, q, C.byref(rows), C.byref(cols), None, 0, C.byref(used))
     if rc != _lib.RZK_OK:
         raise ValueError("malformed Mat encoding")
     slab = np.empty((rows.value, cols.value, N), dtype=np.int64)
-    rc = L.rzk_wire_mat_decode(ptr, buf.size, N, coef_bytes, C.byref(rows), C.byref(cols),
+    rc = L.rzk_wire_mat_decode(ptr, buf.size, N, coef_bytes, q, C.byref(rows), C.byref(cols),
                                C.c_void_p(slab.ctypes.data), rows.value * cols.value, C.byref(used))
     if rc != _lib.RZK_OK:
         raise ValueError("malformed Mat encoding")

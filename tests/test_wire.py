@@ -67,3 +67,25 @@ def test_malformed_inputs_are_rejected():
         wire.mat_encode(np.full((1, 1, N), 2 ** 40, dtype=np.int64), coef_bytes=4)   # does not fit i32
     empty, used = wire.mat_decode(struct.pack("<Q", 0), N)
     assert empty.shape == (0, 0, N) and used == 8
+
+
+def test_decode_range_checks_coefficients_when_given_the_modulus():
+    """A ZqI64 on the wire is its centred representative (src/params.rs:122-127); with q the codec rejects anything
+    else — in particular v + k*2^32, whose low word is an honest value (the verifier kernels test it again)."""
+    q = 3515337053
+    half = (q - 1) // 2
+    n_ring = 8
+    slab = np.zeros((2, 1, n_ring), dtype=np.int64)
+    slab[0, 0, :3] = [half, -half, 7]
+    slab[1, 0, :2] = [-1, 1]
+    data = wire.mat_encode(slab)
+    back, used = wire.mat_decode(data, n_ring, q=q)
+    assert used == len(data) and np.array_equal(back, slab)
+    for bad in (half + 1, -half - 1, 7 + (1 << 32), -(1 << 32), 1 << 62):
+        evil = slab.copy()
+        evil[1, 0, 1] = bad
+        enc = wire.mat_encode(evil)
+        with pytest.raises(ValueError):
+            wire.mat_decode(enc, n_ring, q=q)
+        plain, _ = wire.mat_decode(enc, n_ring)             # q = 0: plain integers (the reference's i32 test ring)
+        assert plain[1, 0, 1] == bad

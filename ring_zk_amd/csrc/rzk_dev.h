@@ -82,6 +82,39 @@ struct Program {
   AddTerm adds[kMaxAdds];
 };
 
+// ---- wave programs (unit_kernel): the default evaluation of a row program -------------------------------------
+// A UNIT is one output row — or a PAIR of rows (A, B) — evaluated by one wavefront over an ordered list of ITEMS;
+// an item is one forward-transformed operand together with what is multiplied into the rows with it:
+//   ITEM_KEY   acc_A += signA * KEY[keyA] (*) X      and / or      acc_B = signB * KEY[keyB] (*) X
+//   ITEM_VEC   acc_A += signA * X(a_op,a_off) (*) X(b_op,b_off)                      (single-row units only)
+// Row B of a pair has exactly one product and its operand is the unit's LAST item, so the transform of that operand
+// is shared (c0 = r0 + K0 r1 + K1 r2 and c1 = r1 + K2 r2 + x of an Open commitment share r2: commit.rs:109-125).
+// While operands are loaded and transformed nothing else is live in registers: the accumulator of row A is parked
+// in LDS between items (one N-word buffer per wavefront, the layout of the resident key), the one of row B exists
+// only from the last item on.  The Garner state between primes lives in a per-wave global scratch line.
+// Rotation terms (TERM_SHIFT), plain additions, the store / zero test and the norm marks stay in Program::rows.
+enum : uint8_t { ITEM_KEY = 0, ITEM_VEC = 1 };
+constexpr uint16_t kNoKey = 0xffff;
+constexpr uint16_t kNoRow = 0xffff;
+struct Item {
+  uint8_t kind;        // ITEM_KEY / ITEM_VEC
+  uint8_t flags;       // TERM_CHECK / TERM_CHECK2: the b operand carries a fused norm mark
+  uint8_t b_op, a_op;
+  uint16_t b_off, a_off;
+  uint16_t keyA, keyB;   // key entries (kNoKey = the item does not feed that row)
+  int8_t signA, signB;
+  uint16_t pad;
+};
+struct Unit {
+  uint16_t rowA, rowB;   // indices into Program::rows; rowB = kNoRow for a single row
+  uint16_t item0, nitems;
+};
+struct WaveProgram {
+  uint32_t nunits, nitems;
+  Unit units[kMaxRows];
+  Item items[kMaxTerms];
+};
+
 // Shared-operand path: the distinct polynomials ("slots") the product terms of a program read, and for
 // each term the slots of its operands.  check[s] != 0: the slot belongs to a norm-checked vector.
 constexpr int kMaxSlots = 512;
@@ -132,10 +165,12 @@ struct LaunchCfg {
   int num_cus;
 };
 
-int launch_row_program(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows, bool has_vec,
-                       bool has_shift, const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf,
-                       const DevTables* d_T, const uint32_t* d_tw, uint32_t* d_scratch, uint8_t* d_flags,
-                       uint64_t batch);
+// units_per_task: how many consecutive units of one batch entry a wavefront evaluates back to back (all of them =
+// one wavefront per proof: equal-cost tasks, no tail)
+int launch_units(int logn, const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, uint32_t nunits,
+                 uint32_t units_per_task, bool has_vec, bool has_shift, const Operands& ops, const uint32_t* d_key_ntt,
+                 const double* d_key_inf, const DevTables* d_T, const uint32_t* d_tw, uint32_t* d_scratch,
+                 uint8_t* d_flags, uint64_t batch);
 int launch_row_program_slots(int logn, const LaunchCfg& cfg, const Program* d_prog, const SlotTable* d_slots,
                              uint32_t nslots, const Operands& ops, const uint32_t* d_key_ntt,
                              const double* d_key_inf, const DevTables* d_T, const uint32_t* d_tw, uint32_t* d_ws,
@@ -157,7 +192,7 @@ int launch_shift_rows(int logn, const LaunchCfg& cfg, const Program* d_prog, uin
 #define RZK_GROUP_GM 4   // accumulators (= rows per group) of row_group_kernel at N <= 1024; at most kGroupMax
 #endif
 inline int group_max_for(int logn) { return logn >= 11 ? 1 : RZK_GROUP_GM; }
-// words of per-wave global scratch the row kernel needs: (max blocks) * 4 waves * 2N (Garner word B, shift sums)
+// words of per-wave global scratch of unit_kernel: (max blocks) * 4 waves * 4N (Garner words A, B of rows A, B)
 size_t row_scratch_words(int logn, int num_cus);
 int launch_key_transform(int logn, const LaunchCfg& cfg, const int64_t* d_key, uint32_t entries,
                          uint32_t* d_key_ntt, const DevTables* d_T, const uint32_t* d_tw);

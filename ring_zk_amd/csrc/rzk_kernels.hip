@@ -535,81 +535,330 @@ __device__ __forceinline__ int primes_for(double bound, const DevTables& T) {
   return __builtin_amdgcn_readfirstlane(np);
 }
 
-#ifndef RZK_ROW_WPB
-#define RZK_ROW_WPB 4        // wavefronts per workgroup of row_kernel
+// =============================================================================================
+// unit_kernel: the default evaluation of a row program (rzk_dev.h, "wave programs").
+//
+// One wavefront evaluates the units of one batch entry.  Per auxiliary prime it walks the unit's items: load the
+// operand (the first prime pass also proves that every coefficient is canonical and measures the norms that fix the
+// number of primes), lift, forward transform, multiply into the rows' accumulators; then inverse transform, fold
+// into the Garner state, and after the last prime finish the row (rotation terms, plain additions, store or zero
+// test, norm marks).  Register discipline: while an operand is loaded and transformed NOTHING else is live —
+//   * the accumulator of row A is parked in LDS (buffer P, N words, key layout: the lane's own 16-byte slots, so
+//     no cross-lane synchronisation) and only materialises in registers with the unit's last item, in place of
+//     the transform it is computed from;
+//   * the accumulator of a pair's row B is born with that last item and parked in P while row A is transformed back;
+//   * the Garner state (one or two words per coefficient and row) lives in a per-wave global scratch line
+//     ([g][lane][4] order, 16-byte accesses; L2 / Infinity-Cache resident), not in registers or LDS;
+//   * rotation terms run after the transforms, accumulating straight into the row's value in registers, with the
+//     2N-word image in the (then idle) slab + P.
+// LDS per wavefront: transposition slab (N + N/32 words) + P (N words) = 8.1 KiB at N = 1024.
+// =============================================================================================
+#ifndef RZK_UNIT_MIN_WAVES
+#define RZK_UNIT_MIN_WAVES 1
 #endif
-#ifndef RZK_ROW_OPAQUE
-#define RZK_ROW_OPAQUE 0     // 1: opaque lane ids in every row_kernel variant (not only the ones with rotation terms)
+#ifndef RZK_UNIT_OPAQUE
+#define RZK_UNIT_OPAQUE 0
 #endif
-template <int LOGN, bool HAS_VEC, bool HAS_SHIFT>
-__global__ void __launch_bounds__(64 * RZK_ROW_WPB, RZK_ROW_MIN_WAVES)
-row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t* __restrict__ key_ntt,
-           const double* __restrict__ key_inf, const DevTables* __restrict__ Tp,
-           const uint32_t* __restrict__ tw_all, uint32_t* __restrict__ scratch, uint8_t* __restrict__ flags,
-           const uint32_t ntasks) {
+
+// x (transform, phase-3 register order) times a resident key entry or a second transform, into row A's accumulator:
+//   init: nothing accumulated yet; to_regs: this is the unit's last item -> the sum replaces x, else it goes to P
+template <int LOGN>
+__device__ __forceinline__ void mac_park(uint32_t* x, const uint4* __restrict__ kp, const uint32_t* mul_regs, bool minus,
+                                         uint4* P4, int lane, bool init, bool to_regs, const PrimeConsts& pc) {
+  constexpr int E = Geo<LOGN>::E;
+#pragma unroll
+  for (int g = 0; g < E / 4; ++g) {
+    uint32_t ks[4];
+    if (kp) {
+      const uint4 kv = kp[g * 64 + lane];
+      ks[0] = kv.x, ks[1] = kv.y, ks[2] = kv.z, ks[3] = kv.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ks[i] = mul_regs[4 * g + i];
+    }
+    uint4 a = make_uint4(0, 0, 0, 0);
+    if (!init) a = P4[g * 64 + lane];
+    uint32_t as[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      as[i] = minus ? mac_sub(as[i], x[4 * g + i], ks[i], pc) : mac_add(as[i], x[4 * g + i], ks[i], pc);
+    if (to_regs) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[4 * g + i] = as[i];
+    } else {
+      P4[g * 64 + lane] = make_uint4(as[0], as[1], as[2], as[3]);
+    }
+  }
+}
+
+// Inverse transform of a finished accumulator and Garner step `pi` of `np` against the row's global state lines.
+// Returns true when the row's value is complete: acc[e] then holds X mod q in [0,q) for coefficient e*64 + lane.
+template <int LOGN, bool OPQ>
+__device__ __forceinline__ bool inverse_fold_global(int pi, int np, uint32_t* acc, int lane, uint32_t* lds,
+                                                    const uint32_t* __restrict__ twi, const PrimeConsts& pc,
+                                                    uint32_t* __restrict__ stA, uint32_t* __restrict__ stB,
+                                                    const DevTables& T) {
+  using G = Geo<LOGN>;
+  constexpr int E = G::E;
+  int li = lane;
+  RZK_OPAQUE(li);
+  wave_inv<LOGN>(acc, li, lds, twi, pc);
+  uint4* __restrict__ A4 = reinterpret_cast<uint4*>(stA);
+  uint4* __restrict__ B4 = reinterpret_cast<uint4*>(stB);
+  if (pi == 0) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = crt_fold0(acc[e], np, T.pc, T.crt);
+    if (np == 1) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[e] = crt_finish_zq(acc[e], 1, T.crt);
+      return true;
+    }
+#pragma unroll
+    for (int g = 0; g < E / 4; ++g) A4[g * 64 + li] = make_uint4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+    return false;
+  }
+  if (pi == 1) {
+#pragma unroll
+    for (int g = 0; g < E / 4; ++g) {
+      const uint4 dv = A4[g * 64 + li];
+      const uint32_t d0[4] = {dv.x, dv.y, dv.z, dv.w};
+      uint32_t va[4], vb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t d1 = crt_digit1(acc[4 * g + i], d0[i], np, T.pc, T.crt);
+        va[i] = crt_value01_modq(d0[i], d1, T.crt);
+        vb[i] = np == 3 ? crt_value01_modp2(d0[i], d1, T.pc, T.crt) : 0u;
+      }
+      if (np == 3) {
+        A4[g * 64 + li] = make_uint4(va[0], va[1], va[2], va[3]);
+        B4[g * 64 + li] = make_uint4(vb[0], vb[1], vb[2], vb[3]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[4 * g + i] = crt_finish_zq(va[i], 2, T.crt);
+      }
+    }
+    return np == 2;
+  }
+#pragma unroll
+  for (int g = 0; g < E / 4; ++g) {
+    const uint4 av = A4[g * 64 + li], bv = B4[g * 64 + li];
+    uint32_t a[4] = {av.x, av.y, av.z, av.w};
+    const uint32_t bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      crt_fold2(acc[4 * g + i], T.pc, T.crt, a[i], bb[i]);
+      acc[4 * g + i] = crt_finish_zq(a[i], 3, T.crt);
+    }
+  }
+  return true;
+}
+
+// u[e] = the row's product sum mod q (coefficient e*64 + lane; zero when the row has no products): rotation terms,
+// plain additions, store / zero test, norm marks of checked additions, canonical-input test of everything loaded.
+template <int LOGN, bool HAS_SHIFT>
+__device__ __forceinline__ void finish_row(uint32_t* u, const Program* __restrict__ prog, const Row row,
+                                           const Operands& ops, uint32_t b, uint32_t bo, int lane, uint32_t* lds,
+                                           const DevTables& T, uint8_t* __restrict__ flags) {
   using G = Geo<LOGN>;
   constexpr int E = G::E;
   constexpr int N = G::N;
+  const uint32_t q = T.crt.q, qhalf = T.crt.qhalf;
+  bool fault = false;
+  if (HAS_SHIFT && row.nshift > 0) {
+    wave_sync();   // slab and P are idle now: they hold the 2N-word image of the rotation terms
+#pragma unroll 1
+    for (uint32_t t = 0; t < row.nshift; ++t) {
+      const Term tm = prog->terms[row.term0 + row.nterms + t];
+      const int64_t* __restrict__ pa = operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N);
+      int32_t a[E];
+      uint32_t abad = 0, amx = 0;
+#pragma unroll
+      for (int e = 0; e < E; ++e) a[e] = canon_lo_mx(pa[G::j_p1(lane, e)], qhalf, abad, amx);
+      fault = fault || canon_fail(abad, amx, qhalf);
+      shift_product<LOGN, false, false>(u, false, tm.sign < 0, a, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane,
+                                        reinterpret_cast<int32_t*>(lds), T, fault);
+    }
+    wave_sync();
+  }
+  constexpr int CH = E < 8 ? E : 8;   // coefficients per lane handled together (bounds the 64-bit values in flight)
+  uint64_t add_sq[4] = {0, 0, 0, 0};
+  uint32_t in_bad = 0, in_mx = 0;
+  int nz = 0;
+#pragma unroll
+  for (int e0 = 0; e0 < E; e0 += CH) {
+#pragma unroll 1
+    for (uint32_t a = 0; a < row.nadds; ++a) {
+      const AddTerm ad = prog->adds[row.add0 + a];
+      const int64_t* __restrict__ src = operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, N);
+      int32_t av[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) av[i] = canon_lo_mx(src[G::j_p1(lane, e0 + i)], qhalf, in_bad, in_mx);
+      if (ad.op & (ADD_CHECK | ADD_CHECK2)) {
+        uint64_t sq = 0;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+          uint32_t aa = (uint32_t)(av[i] < 0 ? -av[i] : av[i]);
+          aa = aa < (1u << 24) ? aa : (1u << 24);
+          sq += (uint64_t)aa * aa;
+        }
+        add_sq[a < 4 ? a : 3] += sq;
+      }
+      if (ad.sign >= 0) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) u[e0 + i] = addq(u[e0 + i], zq_from_centered(av[i], q), q);
+      } else {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) u[e0 + i] = subq(u[e0 + i], zq_from_centered(av[i], q), q);
+      }
+    }
+    if (row.mode == MODE_STORE) {
+      int64_t* __restrict__ dst = const_cast<int64_t*>(operand_ptr(ops, row.out_op, row.out_off, b, bo, N));
+#pragma unroll
+      for (int i = 0; i < CH; ++i) dst[G::j_p1(lane, e0 + i)] = center_from_zq(u[e0 + i], T.crt);
+    } else {
+#pragma unroll
+      for (int i = 0; i < CH; ++i) nz |= (u[e0 + i] != 0);
+    }
+  }
+  if (row.mode != MODE_STORE) {
+    if (__any(nz) && lane == 0) flags[bo] = 0;
+  }
+  if (fault || (row.nadds && canon_fail(in_bad, in_mx, qhalf))) input_fault(ops, flags, bo, lane);
+  if (ops.norm_limit) {
+    // checked additions: the host marks them only among the first four additions of a row
+#pragma unroll 1
+    for (uint32_t a = 0; a < row.nadds && a < 4; ++a) {
+      const uint8_t aop = prog->adds[row.add0 + a].op;
+      if (aop & (ADD_CHECK | ADD_CHECK2)) {
+        uint64_t tot = 0;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) tot = (sl == (int)a) ? add_sq[sl] : tot;
+        tot = wave_sum_u64(tot);
+        if (tot >= ops.norm_limit && lane == 0) fail_check(flags + bo, ops.pad != 0, (aop & ADD_CHECK2) != 0);
+      }
+    }
+  }
+}
+
+template <int LOGN, bool HAS_VEC, bool HAS_SHIFT>
+__global__ void __launch_bounds__(256, RZK_UNIT_MIN_WAVES)
+unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp, const Operands ops,
+            const uint32_t* __restrict__ key_ntt, const double* __restrict__ key_inf, const DevTables* __restrict__ Tp,
+            const uint32_t* __restrict__ tw_all, uint32_t* __restrict__ scratch, uint8_t* __restrict__ flags,
+            const uint32_t ntasks, const uint32_t units_per_task, const uint32_t tasks_per_entry) {
+  using G = Geo<LOGN>;
+  constexpr int E = G::E;
+  constexpr int N = G::N;
+  constexpr bool OPQ = RZK_UNIT_OPAQUE || LOGN >= RZK_OPAQUE_LANE_MIN_LOGN;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // per wave: transposition slab, then Garner state A (one word per coefficient); the two together also hold
-  // the 2N-word image of a shift term, which is finished before the transforms start
-  uint32_t* lds = smem + wave * (G::LDS_WORDS + N);
-  uint32_t* st_lds = lds + G::LDS_WORDS;
-  uint32_t* st_glb = scratch + ((size_t)blockIdx.x * RZK_ROW_WPB + wave) * (2 * N);   // state B, only touched when np == 3
-  uint32_t* st_sh = st_glb + N;                                             // sum of the row's shift terms mod q
+  uint32_t* lds = smem + wave * (G::LDS_WORDS + N);             // transposition slab, then P
+  uint4* P4 = reinterpret_cast<uint4*>(lds + G::LDS_WORDS);     // G::LDS_WORDS * 4 is a multiple of 16 bytes
+  uint32_t* st = scratch + ((size_t)blockIdx.x * 4 + wave) * (size_t)(4 * N);   // [row A | B][word A | B][N]
   const DevTables& T = *Tp;
-  const uint32_t nrows = prog->nrows;
+  const uint32_t qhalf = T.crt.qhalf;
+  const uint32_t nunits = wp->nunits;
 
-  for (uint32_t task = blockIdx.x * RZK_ROW_WPB + wave; task < ntasks; task += gridDim.x * RZK_ROW_WPB) {
-    const uint32_t b = task / nrows;
-    const uint32_t rowi = task - b * nrows;
+  for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
+    const uint32_t b = task / tasks_per_entry;
+    const uint32_t u0 = (task - b * tasks_per_entry) * units_per_task;
+    const uint32_t u1 = u0 + units_per_task < nunits ? u0 + units_per_task : nunits;
     const uint32_t bo = ops.group > 1 ? b / ops.group : b;
-    const Row row = prog->rows[rowi];
-
-    const bool has_shift = HAS_SHIFT && row.nshift > 0;
-    if (has_shift) {
-      // challenge products first (rotations in LDS); their sum mod q is built in the wave's scratch line (every
-      // lane reads and writes only its own coefficients) and waits there for the epilogue
 #pragma unroll 1
-      for (uint32_t t = 0; t < row.nshift; ++t) {
-        const Term tm = prog->terms[row.term0 + row.nterms + t];
-        const int64_t* __restrict__ pa = operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N);
-        const int64_t* __restrict__ pv = operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N);
-        int32_t a[E];
-        uint32_t abad = 0, amx = 0;
+    for (uint32_t ui = u0; ui < u1; ++ui) {
+      const Unit un = wp->units[ui];
+      const Row rowA = prog->rows[un.rowA];
+      const bool pair = un.rowB != kNoRow;
+      if (un.nitems == 0) {   // no products: additions / rotation terms only
+        uint32_t u[E];
 #pragma unroll
-        for (int e = 0; e < E; ++e) a[e] = canon_lo_mx(pa[G::j_p1(lane, e)], T.crt.qhalf, abad, amx);
-        bool fault = canon_fail(abad, amx, T.crt.qhalf);
-        shift_product<LOGN, false, true>(st_sh, t == 0, tm.sign < 0, a, pv, lane, reinterpret_cast<int32_t*>(lds), T,
-                                         fault);
-        if (fault) input_fault(ops, flags, bo, lane);
+        for (int e = 0; e < E; ++e) u[e] = 0;
+        finish_row<LOGN, HAS_SHIFT>(u, prog, rowA, ops, b, bo, lane, lds, T, flags);
+        continue;
       }
-      wave_sync();   // the image is dead: the slab and state words may be overwritten
-    }
-
-    const bool has_terms = row.nterms > 0;
-    int np = kMaxPrimes;
-    if (has_terms) {
-      double bound = 0.0;
+      int np = kMaxPrimes;
+      double boundA = 0.0, boundB = 0.0;
 #pragma unroll 1
       for (int pi = 0; pi < np; ++pi) {
         const PrimeConsts pc = T.pc[pi];
         const uint32_t* __restrict__ twf = tw_all + (size_t)(2 * pi) * kTableLen;
         const bool first = pi == 0;
-        uint32_t acc[E];
-#pragma unroll
-        for (int c = 0; c < E; ++c) acc[c] = 0;
+        uint32_t x[E];      // the current transform; with the last item it becomes row A's accumulator
+        uint32_t accB[E];   // row B's accumulator (pairs only, born with the last item)
+        bool fault = false;
 #pragma unroll 1
-        for (uint32_t t = 0; t < row.nterms; ++t)
-          term_direct<LOGN, HAS_VEC, HAS_SHIFT || RZK_ROW_OPAQUE>(acc, prog->terms[row.term0 + t], ops, b, bo, lane, lds, twf, pc, pi, key_ntt,
-                                     key_inf, first, bound, flags, T.crt.qhalf);
-        if (first) np = primes_for(bound, T);
-        inverse_and_fold<LOGN, HAS_SHIFT || RZK_ROW_OPAQUE>(pi, np, acc, lane, lds, twf + kTableLen, pc, st_lds, st_glb, T);
+        for (uint32_t it = 0; it < un.nitems; ++it) {
+          const Item im = wp->items[un.item0 + it];
+          const bool last = it + 1 == un.nitems;
+          int ln = lane;
+          RZK_OPAQUE(ln);
+          double l1b = 0, infb = 0;
+          uint64_t sumsq = 0;
+          const bool chk = first && (im.flags & (TERM_CHECK | TERM_CHECK2));
+          load_lift<LOGN>(x, operand_ptr(ops, im.b_op, im.b_off, b, bo, N), ln, pc, first, l1b, infb, chk, sumsq, qhalf, fault);
+          if (chk && sumsq >= ops.norm_limit && lane == 0)
+            fail_check(flags + bo, ops.pad != 0, (im.flags & TERM_CHECK2) != 0);
+          wave_fwd<LOGN>(x, ln, lds, twf, pc);
+          if (HAS_VEC && im.kind == ITEM_VEC) {
+            uint32_t xb[E];   // b's transform with N^-1 and the Montgomery factor folded in
+#pragma unroll
+            for (int c = 0; c < E; ++c) xb[c] = csub(mont_lazy(x[c], pc.ninv_r2, pc.p, pc.npinv), pc.p);
+            double l1a = 0, infa = 0;
+            uint64_t unused_sq = 0;
+            load_lift<LOGN>(x, operand_ptr(ops, im.a_op, im.a_off, b, bo, N), ln, pc, first, l1a, infa, false, unused_sq, qhalf,
+                            fault);
+            wave_fwd<LOGN>(x, ln, lds, twf, pc);
+            if (first) {
+              const double p0 = l1a * infb, p1 = infa * l1b;
+              boundA += p0 < p1 ? p0 : p1;
+            }
+            mac_park<LOGN>(x, nullptr, xb, im.signA < 0, P4, ln, it == 0, last, pc);
+          } else {
+            if (pair && im.keyB != kNoKey) {   // row B's only product (the host puts it on the last item)
+              if (first) boundB += key_inf[im.keyB] * l1b;
+              const uint4* __restrict__ kb = reinterpret_cast<const uint4*>(key_ntt + ((size_t)im.keyB * kMaxPrimes + pi) * N);
+#pragma unroll
+              for (int g = 0; g < E / 4; ++g) {
+                const uint4 kv = kb[g * 64 + ln];
+                const uint32_t ks[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                  accB[4 * g + i] = im.signB < 0 ? mac_sub(0u, x[4 * g + i], ks[i], pc) : mac_add(0u, x[4 * g + i], ks[i], pc);
+              }
+            }
+            if (im.keyA != kNoKey) {
+              if (first) boundA += key_inf[im.keyA] * l1b;
+              mac_park<LOGN>(x, reinterpret_cast<const uint4*>(key_ntt + ((size_t)im.keyA * kMaxPrimes + pi) * N), nullptr,
+                             im.signA < 0, P4, ln, it == 0, last, pc);
+            }
+          }
+        }
+        if (fault) input_fault(ops, flags, bo, lane);
+        if (first) np = primes_for(boundA > boundB ? boundA : boundB, T);
+        const uint32_t* __restrict__ twi = twf + kTableLen;
+        if (pair) {   // P is free (row A's sum sits in x): park row B while row A is transformed back
+          int ln = lane;
+          RZK_OPAQUE(ln);
+#pragma unroll
+          for (int g = 0; g < E / 4; ++g)
+            P4[g * 64 + ln] = make_uint4(accB[4 * g], accB[4 * g + 1], accB[4 * g + 2], accB[4 * g + 3]);
+        }
+        if (inverse_fold_global<LOGN, OPQ>(pi, np, x, lane, lds, twi, pc, st, st + N, T))
+          finish_row<LOGN, HAS_SHIFT>(x, prog, rowA, ops, b, bo, lane, lds, T, flags);
+        if (pair) {
+          int ln = lane;
+          RZK_OPAQUE(ln);
+#pragma unroll
+          for (int g = 0; g < E / 4; ++g) {
+            const uint4 v = P4[g * 64 + ln];
+            x[4 * g] = v.x, x[4 * g + 1] = v.y, x[4 * g + 2] = v.z, x[4 * g + 3] = v.w;
+          }
+          if (inverse_fold_global<LOGN, OPQ>(pi, np, x, lane, lds, twi, pc, st + 2 * N, st + 3 * N, T))
+            finish_row<LOGN, false>(x, prog, prog->rows[un.rowB], ops, b, bo, lane, lds, T, flags);
+        }
       }
     }
-    row_epilogue<LOGN>(prog, row, ops, b, bo, lane, has_terms, np, st_lds, T, flags, has_shift ? st_sh : nullptr);
   }
 }
 

@@ -273,6 +273,8 @@ int rzk_wire_mat_decode(const uint8_t* in, size_t len, uint32_t N, uint32_t coef
 
 /* HIP-event timing of the last phase call's dominant kernel is exposed through these counters:
  * accumulated microseconds and launch count of the row kernel since the last reset. */
+/* diagnostic: copies the row kernels' per-wave scratch lines to the host (tools/wave_timeline.py; *total = its size) */
+int rzk_debug_read_scratch(rzk_ctx* ctx, void* dst, size_t bytes, size_t* total);
 int rzk_prof_reset(rzk_ctx* ctx);
 int rzk_prof_enable(rzk_ctx* ctx, int on);
 int rzk_prof_read(rzk_ctx* ctx, double* row_kernel_us, uint64_t* row_kernel_launches);

@@ -68,6 +68,7 @@ SIGNATURES = {
     "rzk_wire_mat_decode": (C.c_int, [_U8, _SZ, C.c_uint32, C.c_uint32, C.c_int64, C.POINTER(C.c_uint32),
                                       C.POINTER(C.c_uint32), _I64, _SZ, C.POINTER(C.c_size_t)]),
     "rzk_bench_ntt_forward_dev": (C.c_double, [_CTX, C.c_int, _U32P, _U32P, _SZ, C.c_int]),
+    "rzk_debug_read_scratch": (C.c_int, [_CTX, C.c_void_p, _SZ, C.POINTER(C.c_size_t)]),
     "rzk_prof_reset": (C.c_int, [_CTX]),
     "rzk_prof_enable": (C.c_int, [_CTX, C.c_int]),
     "rzk_prof_read": (C.c_int, [_CTX, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -19,6 +20,13 @@
 #include "rzk_tables.h"
 
 using namespace rzk;
+
+// table_load (rzk_dev.h) reads these records with scalar loads: they must be naturally aligned inside their tables
+static_assert(sizeof(Term) == 8 && sizeof(AddTerm) == 4 && sizeof(Row) == 16 && sizeof(Item) == 16 && sizeof(Unit) == 8,
+              "program record sizes");
+static_assert(offsetof(Program, rows) % 8 == 0 && offsetof(Program, terms) % 8 == 0 && offsetof(Program, adds) % 4 == 0 &&
+                  offsetof(WaveProgram, units) % 8 == 0 && offsetof(WaveProgram, items) % 8 == 0,
+              "program record alignment");
 
 namespace {
 
@@ -48,6 +56,9 @@ enum ProgId : int {
 struct DevProg {
   Program* d = nullptr;
   uint32_t nrows = 0;
+  WaveProgram* d_wp = nullptr;   // units / items of unit_kernel (the default path)
+  uint32_t nunits = 0;
+  uint32_t work = 0;             // steps (item + inverse trips) of one batch entry per prime pass
   bool has_vec = false;
   // shared-operand path (fwd_slots_kernel + row_slots_kernel), chosen when rows share enough operands
   SlotTable* d_slots = nullptr;
@@ -85,6 +96,7 @@ struct rzk_ctx {
   uint32_t* d_block_scratch = nullptr; // per-workgroup Garner state of the row-block kernel (allocated on first use)
   uint32_t block_min_logn = 11;        // row blocks from this ring degree on (below it row groups do the sharing)
   bool use_groups = true;
+  bool use_pairs = true;               // unit_kernel: pair rows that share their last operand (RZK_PAIRS=0 turns it off, tuning)
   int group_max = 1;                   // rows per group of row_group_kernel (group_max_for; RZK_GROUP_MAX overrides, tuning)
   bool use_shift = true;               // challenge products as signed rotations (shift_row_kernel) instead of transforms
   bool small = false;                  // N < 512: schoolbook kernels (rzk_kernels.hip, "small ring degrees")
@@ -404,13 +416,13 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
         pb.begin_row(8, i, MODE_STORE);
         key_row(c, pb, +1, i, 4, 0);
       }
+      for (uint32_t i = 0; i < l; ++i) {       // a2.y, reduced mod q before it meets g (linear.rs:124-127); placed
+        pb.begin_row(10, i, MODE_STORE);       // next to t = a1.y so that the two rows can share the transform of y
+        key_row(c, pb, +1, n + i, 4, 0);
+      }
       for (uint32_t i = 0; i < n; ++i) {       // linear.rs:121
         pb.begin_row(9, i, MODE_STORE);
         key_row(c, pb, +1, i, 5, 0);
-      }
-      for (uint32_t i = 0; i < l; ++i) {       // a2.y, reduced mod q before it meets g (linear.rs:124-127)
-        pb.begin_row(10, i, MODE_STORE);
-        key_row(c, pb, +1, n + i, 4, 0);
       }
       if (var & 1) {   // fused check_commit_constraint: r -> bit 0, rp -> bit 1 of ok (the two commits of linear.rs:96-97)
         if (!mark_checks(pb, 2, k) || !mark_checks(pb, 3, k, true)) return RZK_E_UNSUPPORTED;
@@ -623,6 +635,64 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
   HIPCHK(c, hipMemcpyAsync(dp.d, &pb.p, sizeof(Program), hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));   // pb.p is a stack object; one-off per (program, shape)
   dp.nrows = pb.p.nrows;
+  if (!c->small) {
+    // Wave program of unit_kernel: one unit per row; two consecutive rows become a PAIR when the second has exactly
+    // one key product and its operand is the last operand of the first (c0 / c1 of a commitment share r_{k-1};
+    // t = a1.y and a2.y share y_{k-1}): that transform is then computed once for both.
+    std::vector<WaveProgram> wpv(1);
+    WaveProgram& wp = wpv[0];
+    std::memset(&wp, 0, sizeof(wp));
+    auto key_only = [&](const Row& rr) {
+      for (uint32_t t = 0; t < rr.nterms; ++t)
+        if ((pb.p.terms[rr.term0 + t].kind & TERM_KIND_MASK) != TERM_KEY) return false;
+      return true;
+    };
+    for (uint32_t r = 0; r < pb.p.nrows;) {
+      const Row& ra = pb.p.rows[r];
+      Unit& un = wp.units[wp.nunits++];
+      un.rowA = (uint16_t)r;
+      un.rowB = kNoRow;
+      un.item0 = (uint16_t)wp.nitems;
+      un.nitems = ra.nterms;
+      for (uint32_t t = 0; t < ra.nterms; ++t) {
+        const Term& tm = pb.p.terms[ra.term0 + t];
+        Item& im = wp.items[wp.nitems++];
+        im.kind = (tm.kind & TERM_KIND_MASK) == TERM_VEC ? ITEM_VEC : ITEM_KEY;
+        im.flags = tm.kind & (TERM_CHECK | TERM_CHECK2);
+        im.b_op = tm.b_op;
+        im.b_off = tm.b_off;
+        im.a_op = tm.a_op;
+        im.a_off = tm.a_off;
+        im.keyA = im.kind == ITEM_KEY ? tm.a_off : 0;
+        im.keyB = kNoKey;
+        im.signA = tm.sign;
+        im.signB = 0;
+      }
+      uint32_t step = 1;
+      if (c->use_pairs && r + 1 < pb.p.nrows && ra.nterms >= 1 && ra.nshift == 0 && key_only(ra)) {
+        const Row& rb = pb.p.rows[r + 1];
+        if (rb.nterms == 1 && rb.nshift == 0 && key_only(rb)) {
+          const Term& tb = pb.p.terms[rb.term0];
+          const Term& ta = pb.p.terms[ra.term0 + ra.nterms - 1];
+          if (tb.b_op == ta.b_op && tb.b_off == ta.b_off) {
+            Item& im = wp.items[wp.nitems - 1];
+            im.keyB = tb.a_off;
+            im.signB = tb.sign;
+            im.flags |= tb.kind & (TERM_CHECK | TERM_CHECK2);
+            un.rowB = (uint16_t)(r + 1);
+            step = 2;
+          }
+        }
+      }
+      r += step;
+    }
+    HIPCHK(c, hipMalloc((void**)&dp.d_wp, sizeof(WaveProgram)));
+    HIPCHK(c, hipMemcpyAsync(dp.d_wp, &wp, sizeof(WaveProgram), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    dp.nunits = wp.nunits;
+    for (uint32_t u = 0; u < wp.nunits; ++u)
+      dp.work += (wp.units[u].nitems ? wp.units[u].nitems : 1u) + (wp.units[u].rowB != kNoRow ? 2u : 1u);
+  }
   for (uint32_t t = 0; t < pb.p.nterms; ++t) dp.has_vec = dp.has_vec || (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_VEC;
   // distinct operands of the product terms ("slots"); when rows share them often enough, transform each
   // once per proof (shared-operand path) instead of once per row
@@ -673,6 +743,7 @@ void drop_programs(rzk_ctx* c) {
     if (kv.second.d) (void)hipFree(kv.second.d);
     if (kv.second.d_slots) (void)hipFree(kv.second.d_slots);
     if (kv.second.d_blocks) (void)hipFree(kv.second.d_blocks);
+    if (kv.second.d_wp) (void)hipFree(kv.second.d_wp);
   }
   c->progs.clear();
 }
@@ -758,8 +829,11 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
                                      flags ? flags + b0 / grp : nullptr, nb, dp.np_store);
     }
   } else {
-    lrc = launch_row_program((int)c->logn, cfg_of(c), dp.d, dp.nrows, dp.has_vec, dp.has_shift, ops, c->d_key_ntt,
-                             c->d_key_inf, c->dT, c->d_tw, c->d_row_scratch, flags, batch);
+    // one wavefront per batch entry (all units back to back: equal-cost tasks, no tail) once the batch alone fills
+    // the chip's wave slots; one unit per task below that
+    const uint32_t upt = batch >= (uint64_t)c->num_cus * 16 ? dp.nunits : 1;
+    lrc = launch_units((int)c->logn, cfg_of(c), dp.d, dp.d_wp, dp.nunits, upt, 2 * dp.work, dp.has_vec, dp.has_shift, ops, c->d_key_ntt,
+                       c->d_key_inf, c->dT, c->d_tw, c->d_row_scratch, flags, batch);
   }
   if (lrc == -2) return fail(c, RZK_E_UNSUPPORTED, "batch * rows must stay below 2^32");
   if (lrc != 0) {
@@ -931,6 +1005,7 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
     if (g >= 1 && g <= (c->logn >= 11 ? 2 : RZK_GROUP_GM)) c->group_max = g;   // bounded by the compiled accumulators
   }
   if (const char* e = std::getenv("RZK_SHIFT")) c->use_shift = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RZK_PAIRS")) c->use_pairs = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_BLOCK_MIN_LOGN")) c->block_min_logn = (uint32_t)std::atoi(e);   // 12 = never
 
   // twiddle tables: 3 primes x {fwd, inv} x kTableLen
@@ -1751,6 +1826,18 @@ double rzk_bench_ntt_forward_dev(rzk_ctx* c, int prime, const uint32_t* in, uint
   (void)hipEventDestroy(e1);
   if (rc != RZK_OK) return (double)rc;
   return (double)ms * 1000.0 / iters;
+}
+
+// Diagnostic: copy of the row-kernel scratch (per-wave lines; builds with -DRZK_STAMPS=1 leave wave time stamps there).
+int rzk_debug_read_scratch(rzk_ctx* c, void* dst, size_t bytes, size_t* total) {
+  if (!c) return RZK_E_ARG;
+  const size_t all = c->d_row_scratch ? row_scratch_words((int)c->logn, c->num_cus) * sizeof(uint32_t) : 0;
+  if (total) *total = all;
+  if (!dst || !bytes) return RZK_OK;
+  if (bytes > all) bytes = all;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(dst, c->d_row_scratch, bytes, hipMemcpyDeviceToHost));
+  return RZK_OK;
 }
 
 int rzk_prof_enable(rzk_ctx* c, int on) {

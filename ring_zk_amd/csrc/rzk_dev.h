@@ -28,6 +28,21 @@ struct DevTables {
 // back once, CRT-reconstructed, reduced to the centred representative mod q, then the additions are
 // applied.  The result is either stored (MODE_STORE) or tested against zero (MODE_ZERO, the
 // `lhs == rhs` of the verifiers, e.g. src/prove/open.rs:173).
+// Program tables (rows, terms, additions, units, items, plans) are written by the host before a launch and never by
+// a kernel, so the kernels may read them through the constant address space: the compiler then uses scalar loads
+// (one s_load per record, no vector-memory latency in the control flow).  The records are 4 / 8 / 16 bytes, naturally
+// aligned inside their tables (static_asserts in rzk_api.cpp).
+#if defined(__HIPCC__)
+template <class Tp>
+__device__ __forceinline__ Tp table_load(const Tp* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const Tp __attribute__((address_space(4))) * cptr_t;
+  return *reinterpret_cast<cptr_t>(reinterpret_cast<uintptr_t>(p));
+#else
+  return *p;
+#endif
+}
+#endif
 constexpr int kMaxOperands = 12;
 constexpr int kMaxRows = 48;
 constexpr int kMaxTerms = 640;
@@ -50,18 +65,18 @@ constexpr uint8_t ADD_CHECK = 0x80;    // in AddTerm::op
 constexpr uint8_t ADD_CHECK2 = 0x40;
 constexpr uint8_t ADD_OP_MASK = 0x3f;
 
-struct Term {
+struct alignas(8) Term {
   uint8_t kind;     // TERM_KEY: KEY[a_off] (*) operand(b_op, b_off);  TERM_VEC: (a_op,a_off) (*) (b_op,b_off)
   int8_t sign;      // +1 / -1
   uint8_t a_op, b_op;
   uint16_t a_off, b_off;
 };
-struct AddTerm {
+struct alignas(4) AddTerm {
   uint8_t op;
   int8_t sign;
   uint16_t off;
 };
-struct Row {
+struct alignas(8) Row {
   uint16_t term0, nterms, add0, nadds;
   uint8_t out_op, mode;
   uint16_t out_off;
@@ -96,7 +111,7 @@ struct Program {
 enum : uint8_t { ITEM_KEY = 0, ITEM_VEC = 1 };
 constexpr uint16_t kNoKey = 0xffff;
 constexpr uint16_t kNoRow = 0xffff;
-struct Item {
+struct alignas(8) Item {
   uint8_t kind;        // ITEM_KEY / ITEM_VEC
   uint8_t flags;       // TERM_CHECK / TERM_CHECK2: the b operand carries a fused norm mark
   uint8_t b_op, a_op;
@@ -105,7 +120,7 @@ struct Item {
   int8_t signA, signB;
   uint16_t pad;
 };
-struct Unit {
+struct alignas(8) Unit {
   uint16_t rowA, rowB;   // indices into Program::rows; rowB = kNoRow for a single row
   uint16_t item0, nitems;
 };
@@ -167,10 +182,11 @@ struct LaunchCfg {
 
 // units_per_task: how many consecutive units of one batch entry a wavefront evaluates back to back (all of them =
 // one wavefront per proof: equal-cost tasks, no tail)
+// work_per_entry: transforms one batch entry costs at two primes (the progress priorities only need an estimate)
 int launch_units(int logn, const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, uint32_t nunits,
-                 uint32_t units_per_task, bool has_vec, bool has_shift, const Operands& ops, const uint32_t* d_key_ntt,
-                 const double* d_key_inf, const DevTables* d_T, const uint32_t* d_tw, uint32_t* d_scratch,
-                 uint8_t* d_flags, uint64_t batch);
+                 uint32_t units_per_task, uint32_t work_per_entry, bool has_vec, bool has_shift, const Operands& ops,
+                 const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* d_T, const uint32_t* d_tw,
+                 uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch);
 int launch_row_program_slots(int logn, const LaunchCfg& cfg, const Program* d_prog, const SlotTable* d_slots,
                              uint32_t nslots, const Operands& ops, const uint32_t* d_key_ntt,
                              const double* d_key_inf, const DevTables* d_T, const uint32_t* d_tw, uint32_t* d_ws,

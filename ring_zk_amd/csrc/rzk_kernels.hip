@@ -108,14 +108,11 @@ __device__ __forceinline__ int32_t canon_lo_mx(int64_t c, uint32_t qhalf, uint32
   mx = lo > mx ? lo : mx;
   return (int32_t)c;
 }
-// the same for a 16-byte load of two coefficients (lo0, hi0, lo1, hi1)
-__device__ __forceinline__ void canon_pair(const int4 t, uint32_t qhalf, uint32_t& bad, uint32_t& mx) {
-  const uint64_t s0 = (((uint64_t)(uint32_t)t.y << 32) | (uint32_t)t.x) + qhalf;
-  const uint64_t s1 = (((uint64_t)(uint32_t)t.w << 32) | (uint32_t)t.z) + qhalf;
-  bad |= (uint32_t)(s0 >> 32) | (uint32_t)(s1 >> 32);
-  const uint32_t l0 = (uint32_t)s0, l1 = (uint32_t)s1;
-  mx = l0 > mx ? l0 : mx;
-  mx = l1 > mx ? l1 : mx;
+// the same for a 16-byte load of two coefficients
+__device__ __forceinline__ void canon_pair(const longlong2 t, uint32_t qhalf, uint32_t& bad, uint32_t& mx, int32_t& lo0,
+                                           int32_t& lo1) {
+  lo0 = canon_lo_mx(t.x, qhalf, bad, mx);
+  lo1 = canon_lo_mx(t.y, qhalf, bad, mx);
 }
 // wave-uniform verdict of the per-lane accumulators (mx holds max (lo + h) mod 2^32, canonical <=> <= 2h)
 __device__ __forceinline__ bool canon_fail(uint32_t bad, uint32_t mx, uint32_t qhalf) {
@@ -235,14 +232,9 @@ template <int LOGN>
 __device__ __forceinline__ void load_pairs(int32_t* v, const int64_t* __restrict__ src, int lane, uint32_t qhalf,
                                            uint32_t& bad, uint32_t& mx) {
   using S = ShiftGeo<LOGN>;
-  const int4* __restrict__ p = reinterpret_cast<const int4*>(src);
+  const longlong2* __restrict__ p = reinterpret_cast<const longlong2*>(src);
 #pragma unroll
-  for (int g = 0; g < S::G; ++g) {
-    const int4 t = p[g * 64 + lane];   // coefficients g*128 + 2*lane, +1 (two int64)
-    canon_pair(t, qhalf, bad, mx);
-    v[2 * g] = t.x;
-    v[2 * g + 1] = t.z;
-  }
+  for (int g = 0; g < S::G; ++g) canon_pair(p[g * 64 + lane], qhalf, bad, mx, v[2 * g], v[2 * g + 1]);   // coefficients g*128 + 2*lane, +1
 }
 
 #ifndef RZK_SHIFT_H
@@ -270,12 +262,63 @@ __device__ __forceinline__ void shift_scan(int64_t* acc, const int32_t* a, int l
 // (Taking two non-zeros per trip, or sixteen outputs per scan, to keep more LDS reads in flight was measured
 // slower: the extra registers cost a wave per SIMD.)
 
+// Build the wave's 2N-word extended image of v (ShiftGeo, rzk_core.h) straight from global memory, in two rolled
+// halves so that only E/2 sixty-four-bit coefficients are in flight at a time.  measure: this is the first fill —
+// it also proves that v is canonical (canon_lo) and returns max |v| over the lane's coefficients.
+template <int LOGN, bool PAIR>
+__device__ __forceinline__ void shift_fill_from(const int64_t* __restrict__ pv, int lane, int32_t* ext, int part,
+                                                bool measure, uint32_t qhalf, uint32_t& bad, uint32_t& mx,
+                                                uint32_t& maxabs) {
+  using S = ShiftGeo<LOGN, PAIR>;
+  constexpr int H = S::E / 2;               // registers per half; off(h*H + i) = off(i) + h * 32 * E in both layouts
+  constexpr int HOFF = 32 * S::E;
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    int32_t vh[H];
+    if (PAIR) {
+      const longlong2* __restrict__ p = reinterpret_cast<const longlong2*>(pv) + (size_t)h * (H / 2) * 64;
+#pragma unroll
+      for (int g = 0; g < H / 2; ++g) {
+        const longlong2 t = p[g * 64 + lane];   // coefficients (h*H/2 + g)*128 + 2*lane, +1
+        if (measure) {
+          canon_pair(t, qhalf, bad, mx, vh[2 * g], vh[2 * g + 1]);
+        } else {
+          vh[2 * g] = (int32_t)t.x;
+          vh[2 * g + 1] = (int32_t)t.y;
+        }
+      }
+    } else {
+      const int64_t* __restrict__ p = pv + (size_t)h * H * 64;
+#pragma unroll
+      for (int i = 0; i < H; ++i) {
+        const int64_t c = p[i * 64 + lane];
+        vh[i] = measure ? canon_lo_mx(c, qhalf, bad, mx) : (int32_t)c;
+      }
+    }
+    if (measure) {
+#pragma unroll
+      for (int i = 0; i < H; ++i) {
+        const uint32_t vv = (uint32_t)(vh[i] < 0 ? -vh[i] : vh[i]);
+        maxabs = vv > maxabs ? vv : maxabs;
+      }
+    }
+    int32_t* base = ext + S::lane_base(lane) + h * HOFF;
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+      const int32_t a = shift_part(vh[i], part);
+      base[S::N + S::off(i)] = a;
+      base[S::off(i)] = -a;
+    }
+  }
+}
+
 // res[] (in [0,q)) +/-= (a (*) v) mod q for one product term; a[] holds the multiplier's low words in layout
 // PAIR, pv points at the other operand.  ext: the wave's 2N-word LDS image.  Wave-uniform control flow.
 // TO_MEM: res is a per-wave line in global memory indexed by coefficient (each lane touches only its own
 // coefficients) and `fresh` says that it holds nothing yet; otherwise res are the lane's E registers.
 // Sums are exact 64-bit integers (v_mad_i64_i32) as long as |a|_1 |v|_inf < 2^62; beyond that v goes in as
 // two 16-bit halves.  Eight of a lane's outputs are accumulated at a time (register budget).
+// fault: set when v holds a non-canonical coefficient (the caller tests `a`).
 template <int LOGN, bool PAIR, bool TO_MEM>
 __device__ __forceinline__ void shift_product(uint32_t* res, bool fresh, bool minus, const int32_t* a,
                                               const int64_t* __restrict__ pv, int lane, int32_t* ext,
@@ -284,36 +327,25 @@ __device__ __forceinline__ void shift_product(uint32_t* res, bool fresh, bool mi
   constexpr int E = S::E;
   constexpr int H = RZK_SHIFT_H < E ? RZK_SHIFT_H : E;   // outputs per scan; chunk c covers registers c*H .. c*H+H-1
   constexpr int NCH = E / H;
-  const uint32_t q = T.crt.q;
-  int npass = 1;
+  const uint32_t q = T.crt.q, qhalf = T.crt.qhalf;
+  // optimistic first fill with the whole values; it also measures v
+  uint32_t vbad = 0, vmx = 0, maxv = 0;
+  wave_sync();   // earlier reads of the image are done before it is overwritten
+  shift_fill_from<LOGN, PAIR>(pv, lane, ext, SHIFT_WHOLE, true, qhalf, vbad, vmx, maxv);
+  fault = fault || canon_fail(vbad, vmx, qhalf);
+  uint64_t suma = 0;
+#pragma unroll
+  for (int i = 0; i < E; ++i) suma += (uint32_t)(a[i] < 0 ? -a[i] : a[i]);
+  const double bound = (double)wave_sum_u64(suma) * (double)wave_max_u32(maxv);   // |exact product|_inf
+  const int npass = __builtin_amdgcn_readfirstlane(bound < 4.0e18 ? 1 : 2);        // 4.0e18 < 2^62
 #pragma unroll 1
   for (int pass = 0; pass < npass; ++pass) {
-    {
-      int32_t v[E];
-      uint32_t vbad = 0, vmx = 0;
-      if (PAIR) {
-        load_pairs<LOGN>(v, pv, lane, T.crt.qhalf, vbad, vmx);
-      } else {
-#pragma unroll
-        for (int i = 0; i < E; ++i) v[i] = canon_lo_mx(pv[S::j(lane, i)], T.crt.qhalf, vbad, vmx);
-      }
-      if (pass == 0) {
-        fault = fault || canon_fail(vbad, vmx, T.crt.qhalf);
-        uint64_t suma = 0;
-        uint32_t maxv = 0;
-#pragma unroll
-        for (int i = 0; i < E; ++i) {
-          suma += (uint32_t)(a[i] < 0 ? -a[i] : a[i]);
-          const uint32_t vv = (uint32_t)(v[i] < 0 ? -v[i] : v[i]);
-          maxv = vv > maxv ? vv : maxv;
-        }
-        const double bound = (double)wave_sum_u64(suma) * (double)wave_max_u32(maxv);   // |exact product|_inf
-        npass = __builtin_amdgcn_readfirstlane(bound < 4.0e18 ? 1 : 2);                  // 4.0e18 < 2^62
-      }
-      wave_sync();   // earlier reads of the image are done before it is overwritten
-      shift_fill<LOGN, PAIR>(v, lane, ext, npass == 1 ? SHIFT_WHOLE : (pass == 0 ? SHIFT_LOW16 : SHIFT_HIGH16));
+    if (npass == 2) {   // (never for a sparse +-1 challenge) the image is rebuilt from 16-bit halves
+      uint32_t u0 = 0, u1 = 0, u2 = 0;
       wave_sync();
+      shift_fill_from<LOGN, PAIR>(pv, lane, ext, pass == 0 ? SHIFT_LOW16 : SHIFT_HIGH16, false, qhalf, u0, u1, u2);
     }
+    wave_sync();
 #pragma unroll 1
     for (int ch = 0; ch < NCH; ++ch) {
       int64_t acc[H];
@@ -556,32 +588,78 @@ __device__ __forceinline__ int primes_for(double bound, const DevTables& T) {
 #ifndef RZK_UNIT_MIN_WAVES
 #define RZK_UNIT_MIN_WAVES 1
 #endif
+#ifndef RZK_STAMPS
+#define RZK_STAMPS 0
+#endif
+#ifndef RZK_FAIR_PRIO
+#define RZK_FAIR_PRIO 1
+#endif
+#if RZK_STAMPS   // section timers of the diagnostic build: wall cycles a wave spends per kind of step
+#define RZK_T0() const uint64_t t_sec0 = __builtin_amdgcn_s_memtime()
+#define RZK_T1(acc) acc += __builtin_amdgcn_s_memtime() - t_sec0
+#else
+#define RZK_T0() do { } while (0)
+#define RZK_T1(acc) do { } while (0)
+#endif
 #ifndef RZK_UNIT_OPAQUE
-#define RZK_UNIT_OPAQUE 0
+#define RZK_UNIT_OPAQUE 1   // opaque lane ids in unit_kernel: stops hoisting of lane-dependent addresses (91 vs 137 VGPRs at N = 1024)
 #endif
 
-// x (transform, phase-3 register order) times a resident key entry or a second transform, into row A's accumulator:
-//   init: nothing accumulated yet; to_regs: this is the unit's last item -> the sum replaces x, else it goes to P
-template <int LOGN>
-__device__ __forceinline__ void mac_park(uint32_t* x, const uint4* __restrict__ kp, const uint32_t* mul_regs, bool minus,
-                                         uint4* P4, int lane, bool init, bool to_regs, const PrimeConsts& pc) {
+// Fair progress among the wavefronts that share a SIMD.  The VALU arbiter serves the highest priority first and,
+// among equals, the OLDEST wave: left alone, the four waves of a SIMD finish one after the other (measured at
+// N = 1024, one proof per wave: 84 / 105 / 128 / 143 us) and the last one runs its tail alone, with nothing to hide
+// its memory latency behind.  Each wave therefore lowers its priority as it advances through its share of the launch
+// (quarter by quarter: s_setprio has four levels), so that laggards are served first and all waves stay resident
+// until the end.  Speed only: priorities never affect results.
+__device__ __forceinline__ void set_priority_level(uint32_t level) {   // 0 = most urgent
+  if (level == 0) __builtin_amdgcn_s_setprio(3);
+  else if (level == 1) __builtin_amdgcn_s_setprio(2);
+  else if (level == 2) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+}
+__device__ __forceinline__ void set_progress_priority(uint32_t done, uint32_t total) {
+#if RZK_FAIR_PRIO
+  set_priority_level(__builtin_amdgcn_readfirstlane(total ? (done * 4u) / total : 0u));
+#else
+  (void)done, (void)total;
+#endif
+}
+// When a workgroup fills the CU (16 waves: the four waves of every SIMD are workgroup mates) the waves of a SIMD rank
+// themselves exactly: each publishes the work it has left in an LDS word and takes the priority of its rank (most
+// work left = most urgent), so all four reach the end of the launch together.
+struct FairTable {
+  uint32_t left[4][4];   // [SIMD][slot]: steps the wave still has to do (0: finished / no wave)
+  uint32_t count[4];     // slots handed out per SIMD
+};
+__device__ __forceinline__ void set_rank_priority(FairTable* ft, uint32_t simd, uint32_t slot, uint32_t left, int lane) {
+#if RZK_FAIR_PRIO
+  if (lane == 0) __hip_atomic_store(&ft->left[simd][slot], left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  uint32_t rank = 0;
+#pragma unroll
+  for (uint32_t m = 0; m < 4; ++m) {
+    const uint32_t o = __hip_atomic_load(&ft->left[simd][m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    rank += (m != slot) && (o > left || (o == left && m < slot));
+  }
+  set_priority_level(__builtin_amdgcn_readfirstlane(rank));
+#else
+  (void)ft, (void)simd, (void)slot, (void)left, (void)lane;
+#endif
+}
+
+// x (transform, phase-3 register order) times `mul` (a resident key entry or a second transform, in registers), into
+// row A's accumulator.  init: nothing accumulated yet; to_regs: the unit's last item -> the sum replaces x, else -> P
+template <int LOGN, bool to_regs>
+__device__ __forceinline__ void mac_park(uint32_t* x, const uint32_t* mul, bool minus, uint4* P4, int lane, bool init,
+                                         const PrimeConsts& pc) {
   constexpr int E = Geo<LOGN>::E;
 #pragma unroll
   for (int g = 0; g < E / 4; ++g) {
-    uint32_t ks[4];
-    if (kp) {
-      const uint4 kv = kp[g * 64 + lane];
-      ks[0] = kv.x, ks[1] = kv.y, ks[2] = kv.z, ks[3] = kv.w;
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) ks[i] = mul_regs[4 * g + i];
-    }
     uint4 a = make_uint4(0, 0, 0, 0);
     if (!init) a = P4[g * 64 + lane];
     uint32_t as[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      as[i] = minus ? mac_sub(as[i], x[4 * g + i], ks[i], pc) : mac_add(as[i], x[4 * g + i], ks[i], pc);
+      as[i] = minus ? mac_sub(as[i], x[4 * g + i], mul[4 * g + i], pc) : mac_add(as[i], x[4 * g + i], mul[4 * g + i], pc);
     if (to_regs) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) x[4 * g + i] = as[i];
@@ -602,9 +680,29 @@ __device__ __forceinline__ bool inverse_fold_global(int pi, int np, uint32_t* ac
   constexpr int E = G::E;
   int li = lane;
   RZK_OPAQUE(li);
-  wave_inv<LOGN>(acc, li, lds, twi, pc);
   uint4* __restrict__ A4 = reinterpret_cast<uint4*>(stA);
   uint4* __restrict__ B4 = reinterpret_cast<uint4*>(stB);
+  // the state words this step needs are requested before the transform, which hides their latency
+  // (N <= 1024; at N = 2048 a lane holds 32 coefficients and the registers are not there)
+  constexpr bool EARLY = LOGN <= 10;
+  uint4 sa[E / 4], sb[E / 4];
+  if (EARLY && pi >= 1) {
+#pragma unroll
+    for (int g = 0; g < E / 4; ++g) sa[g] = A4[g * 64 + li];
+  }
+  if (EARLY && pi == 2) {
+#pragma unroll
+    for (int g = 0; g < E / 4; ++g) sb[g] = B4[g * 64 + li];
+  }
+  wave_inv<LOGN>(acc, li, lds, twi, pc);
+  if (!EARLY && pi >= 1) {
+#pragma unroll
+    for (int g = 0; g < E / 4; ++g) sa[g] = A4[g * 64 + li];
+  }
+  if (!EARLY && pi == 2) {
+#pragma unroll
+    for (int g = 0; g < E / 4; ++g) sb[g] = B4[g * 64 + li];
+  }
   if (pi == 0) {
 #pragma unroll
     for (int e = 0; e < E; ++e) acc[e] = crt_fold0(acc[e], np, T.pc, T.crt);
@@ -620,7 +718,7 @@ __device__ __forceinline__ bool inverse_fold_global(int pi, int np, uint32_t* ac
   if (pi == 1) {
 #pragma unroll
     for (int g = 0; g < E / 4; ++g) {
-      const uint4 dv = A4[g * 64 + li];
+      const uint4 dv = sa[g];
       const uint32_t d0[4] = {dv.x, dv.y, dv.z, dv.w};
       uint32_t va[4], vb[4];
 #pragma unroll
@@ -641,7 +739,7 @@ __device__ __forceinline__ bool inverse_fold_global(int pi, int np, uint32_t* ac
   }
 #pragma unroll
   for (int g = 0; g < E / 4; ++g) {
-    const uint4 av = A4[g * 64 + li], bv = B4[g * 64 + li];
+    const uint4 av = sa[g], bv = sb[g];
     uint32_t a[4] = {av.x, av.y, av.z, av.w};
     const uint32_t bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
@@ -653,34 +751,24 @@ __device__ __forceinline__ bool inverse_fold_global(int pi, int np, uint32_t* ac
   return true;
 }
 
-// u[e] = the row's product sum mod q (coefficient e*64 + lane; zero when the row has no products): rotation terms,
-// plain additions, store / zero test, norm marks of checked additions, canonical-input test of everything loaded.
-template <int LOGN, bool HAS_SHIFT>
+// u[e] = the row's product sum mod q (coefficient e*64 + lane; zero when the row has no products): adds the sum of
+// the row's rotation terms (st_sh, left in the wave's scratch line by the same lanes), the plain additions, then
+// store / zero test, norm marks of checked additions, canonical-input test of everything loaded.
+template <int LOGN>
 __device__ __forceinline__ void finish_row(uint32_t* u, const Program* __restrict__ prog, const Row row,
-                                           const Operands& ops, uint32_t b, uint32_t bo, int lane, uint32_t* lds,
-                                           const DevTables& T, uint8_t* __restrict__ flags) {
+                                           const Operands& ops, uint32_t b, uint32_t bo, int lane, const DevTables& T,
+                                           uint8_t* __restrict__ flags, const uint32_t* __restrict__ st_sh) {
   using G = Geo<LOGN>;
   constexpr int E = G::E;
   constexpr int N = G::N;
   const uint32_t q = T.crt.q, qhalf = T.crt.qhalf;
-  bool fault = false;
-  if (HAS_SHIFT && row.nshift > 0) {
-    wave_sync();   // slab and P are idle now: they hold the 2N-word image of the rotation terms
-#pragma unroll 1
-    for (uint32_t t = 0; t < row.nshift; ++t) {
-      const Term tm = prog->terms[row.term0 + row.nterms + t];
-      const int64_t* __restrict__ pa = operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N);
-      int32_t a[E];
-      uint32_t abad = 0, amx = 0;
+  if (st_sh) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) a[e] = canon_lo_mx(pa[G::j_p1(lane, e)], qhalf, abad, amx);
-      fault = fault || canon_fail(abad, amx, qhalf);
-      shift_product<LOGN, false, false>(u, false, tm.sign < 0, a, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane,
-                                        reinterpret_cast<int32_t*>(lds), T, fault);
-    }
-    wave_sync();
+    for (int e = 0; e < E; ++e) u[e] = addq(u[e], st_sh[G::j_p1(lane, e)], q);
   }
-  constexpr int CH = E < 8 ? E : 8;   // coefficients per lane handled together (bounds the 64-bit values in flight)
+  // An addition is loaded with up to 16 of a lane's coefficients in flight (a row's wall time is dominated by how
+  // often it waits for HBM; 16 sixty-four-bit values are what the register budget of 4 waves per SIMD leaves room for).
+  constexpr int CH = E < 16 ? E : 16;
   uint64_t add_sq[4] = {0, 0, 0, 0};
   uint32_t in_bad = 0, in_mx = 0;
   int nz = 0;
@@ -688,7 +776,7 @@ __device__ __forceinline__ void finish_row(uint32_t* u, const Program* __restric
   for (int e0 = 0; e0 < E; e0 += CH) {
 #pragma unroll 1
     for (uint32_t a = 0; a < row.nadds; ++a) {
-      const AddTerm ad = prog->adds[row.add0 + a];
+      const AddTerm ad = table_load(&prog->adds[row.add0 + a]);
       const int64_t* __restrict__ src = operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, N);
       int32_t av[CH];
 #pragma unroll
@@ -701,7 +789,9 @@ __device__ __forceinline__ void finish_row(uint32_t* u, const Program* __restric
           aa = aa < (1u << 24) ? aa : (1u << 24);
           sq += (uint64_t)aa * aa;
         }
-        add_sq[a < 4 ? a : 3] += sq;
+        const uint32_t slot = a < 4 ? a : 3;
+#pragma unroll
+        for (int sl = 0; sl < 4; ++sl) add_sq[sl] += (sl == (int)slot) ? sq : 0ull;
       }
       if (ad.sign >= 0) {
 #pragma unroll
@@ -723,12 +813,12 @@ __device__ __forceinline__ void finish_row(uint32_t* u, const Program* __restric
   if (row.mode != MODE_STORE) {
     if (__any(nz) && lane == 0) flags[bo] = 0;
   }
-  if (fault || (row.nadds && canon_fail(in_bad, in_mx, qhalf))) input_fault(ops, flags, bo, lane);
+  if (row.nadds && canon_fail(in_bad, in_mx, qhalf)) input_fault(ops, flags, bo, lane);
   if (ops.norm_limit) {
     // checked additions: the host marks them only among the first four additions of a row
 #pragma unroll 1
     for (uint32_t a = 0; a < row.nadds && a < 4; ++a) {
-      const uint8_t aop = prog->adds[row.add0 + a].op;
+      const uint8_t aop = table_load(&prog->adds[row.add0 + a]).op;
       if (aop & (ADD_CHECK | ADD_CHECK2)) {
         uint64_t tot = 0;
 #pragma unroll
@@ -740,12 +830,20 @@ __device__ __forceinline__ void finish_row(uint32_t* u, const Program* __restric
   }
 }
 
+// Wavefronts per workgroup: 16 (the whole CU: exact fairness among SIMD mates, see set_rank_priority) up to N = 1024;
+// 4 at N = 2048, where 16 slabs do not fit the CU's LDS.
+template <int LOGN>
+struct UnitCfg {
+  static constexpr int WPB = LOGN <= 10 ? 16 : 4;
+};
+
 template <int LOGN, bool HAS_VEC, bool HAS_SHIFT>
-__global__ void __launch_bounds__(256, RZK_UNIT_MIN_WAVES)
+__global__ void __launch_bounds__(64 * UnitCfg<LOGN>::WPB)
 unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp, const Operands ops,
             const uint32_t* __restrict__ key_ntt, const double* __restrict__ key_inf, const DevTables* __restrict__ Tp,
             const uint32_t* __restrict__ tw_all, uint32_t* __restrict__ scratch, uint8_t* __restrict__ flags,
-            const uint32_t ntasks, const uint32_t units_per_task, const uint32_t tasks_per_entry) {
+            const uint32_t ntasks, const uint32_t units_per_task, const uint32_t tasks_per_entry,
+            const uint32_t work_per_task) {
   using G = Geo<LOGN>;
   constexpr int E = G::E;
   constexpr int N = G::N;
@@ -753,113 +851,235 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
   const int lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int WPB = UnitCfg<LOGN>::WPB;
+  constexpr bool RANKED = WPB == 16;
   uint32_t* lds = smem + wave * (G::LDS_WORDS + N);             // transposition slab, then P
   uint4* P4 = reinterpret_cast<uint4*>(lds + G::LDS_WORDS);     // G::LDS_WORDS * 4 is a multiple of 16 bytes
-  uint32_t* st = scratch + ((size_t)blockIdx.x * 4 + wave) * (size_t)(4 * N);   // [row A | B][word A | B][N]
+  FairTable* ft = reinterpret_cast<FairTable*>(smem + WPB * (G::LDS_WORDS + N));
+  uint32_t my_simd = 0, my_slot = 0;
+  if (RANKED) {
+    if (threadIdx.x < sizeof(FairTable) / 4) reinterpret_cast<uint32_t*>(ft)[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    my_simd = (hwid >> 4) & 3u;
+    uint32_t sl = 0;
+    if (lane == 0) sl = __hip_atomic_fetch_add(&ft->count[my_simd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    my_slot = __builtin_amdgcn_readfirstlane(sl) & 3u;
+  }
+  // per-wave global scratch: Garner words [row A | B][word A | B][N], then the sum of row A's rotation terms
+  uint32_t* st = scratch + ((size_t)blockIdx.x * WPB + wave) * (size_t)(5 * N + 16);
+  uint32_t* st_sh = st + 4 * N;
+#if RZK_STAMPS   // diagnostic build only (tools/wave_timeline.py): when each wavefront ran and where
+  const uint64_t stamp0 = __builtin_amdgcn_s_memrealtime();
+  const uint64_t cyc0 = __builtin_amdgcn_s_memtime();
+  uint64_t t_load = 0, t_fwd = 0, t_mac = 0, t_inv = 0, t_fin = 0;
+#endif
   const DevTables& T = *Tp;
   const uint32_t qhalf = T.crt.qhalf;
   const uint32_t nunits = wp->nunits;
 
-  for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
+  // progress of this wave through its share of the launch, in transforms (work_per_task: the host's estimate)
+  const uint32_t first_task = blockIdx.x * WPB + wave;
+  const uint32_t my_tasks = first_task < ntasks ? (ntasks - first_task + gridDim.x * WPB - 1) / (gridDim.x * WPB) : 0;
+  const uint32_t work_total = my_tasks * work_per_task;
+  uint32_t work_done = 0;
+#define RZK_STEP_PRIORITY()                                                                                  \
+  do {                                                                                                       \
+    if (RANKED) set_rank_priority(ft, my_simd, my_slot, work_total > work_done ? work_total - work_done : 1u, lane); \
+    else set_progress_priority(work_done, work_total);                                                        \
+    ++work_done;                                                                                             \
+  } while (0)
+
+  for (uint32_t task = first_task; task < ntasks; task += gridDim.x * WPB) {
     const uint32_t b = task / tasks_per_entry;
     const uint32_t u0 = (task - b * tasks_per_entry) * units_per_task;
     const uint32_t u1 = u0 + units_per_task < nunits ? u0 + units_per_task : nunits;
     const uint32_t bo = ops.group > 1 ? b / ops.group : b;
 #pragma unroll 1
     for (uint32_t ui = u0; ui < u1; ++ui) {
-      const Unit un = wp->units[ui];
-      const Row rowA = prog->rows[un.rowA];
+      const Unit un = table_load(&wp->units[ui]);
+      const Row rowA = table_load(&prog->rows[un.rowA]);
       const bool pair = un.rowB != kNoRow;
-      if (un.nitems == 0) {   // no products: additions / rotation terms only
-        uint32_t u[E];
+      const bool null_unit = un.nitems == 0;   // no products: additions / rotation terms only
+      const bool has_shift = HAS_SHIFT && rowA.nshift > 0;
+      if (has_shift) {
+        // challenge products first (rotations, image in slab + P); their sum mod q is built in the wave's scratch line
+        // (every lane reads and writes only its own coefficients) and waits there for finish_row
+        bool fault = false;
+#pragma unroll 1
+        for (uint32_t t = 0; t < rowA.nshift; ++t) {
+          const Term tm = table_load(&prog->terms[rowA.term0 + rowA.nterms + t]);
+          const int64_t* __restrict__ pa = operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N);
+          int32_t a[E];
+          uint32_t abad = 0, amx = 0;
 #pragma unroll
-        for (int e = 0; e < E; ++e) u[e] = 0;
-        finish_row<LOGN, HAS_SHIFT>(u, prog, rowA, ops, b, bo, lane, lds, T, flags);
-        continue;
+          for (int e = 0; e < E; ++e) a[e] = canon_lo_mx(pa[G::j_p1(lane, e)], qhalf, abad, amx);
+          fault = fault || canon_fail(abad, amx, qhalf);
+          shift_product<LOGN, false, true>(st_sh, t == 0, tm.sign < 0, a, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane,
+                                           reinterpret_cast<int32_t*>(lds), T, fault);
+        }
+        if (fault) input_fault(ops, flags, bo, lane);
+        wave_sync();   // the image is dead: slab and P may be overwritten
       }
-      int np = kMaxPrimes;
+      int np = null_unit ? 1 : kMaxPrimes;
+      const uint32_t nit = null_unit ? 1u : (uint32_t)un.nitems;
       double boundA = 0.0, boundB = 0.0;
 #pragma unroll 1
       for (int pi = 0; pi < np; ++pi) {
         const PrimeConsts pc = T.pc[pi];
         const uint32_t* __restrict__ twf = tw_all + (size_t)(2 * pi) * kTableLen;
         const bool first = pi == 0;
-        uint32_t x[E];      // the current transform; with the last item it becomes row A's accumulator
-        uint32_t accB[E];   // row B's accumulator (pairs only, born with the last item)
         bool fault = false;
 #pragma unroll 1
-        for (uint32_t it = 0; it < un.nitems; ++it) {
-          const Item im = wp->items[un.item0 + it];
-          const bool last = it + 1 == un.nitems;
+        for (uint32_t it = 0; it < nit; ++it) {
+          // every array below is local to one trip: nothing is carried in registers from item to item
+          const bool last = it + 1 == nit;
+          RZK_STEP_PRIORITY();
           int ln = lane;
           RZK_OPAQUE(ln);
-          double l1b = 0, infb = 0;
-          uint64_t sumsq = 0;
-          const bool chk = first && (im.flags & (TERM_CHECK | TERM_CHECK2));
-          load_lift<LOGN>(x, operand_ptr(ops, im.b_op, im.b_off, b, bo, N), ln, pc, first, l1b, infb, chk, sumsq, qhalf, fault);
-          if (chk && sumsq >= ops.norm_limit && lane == 0)
-            fail_check(flags + bo, ops.pad != 0, (im.flags & TERM_CHECK2) != 0);
-          wave_fwd<LOGN>(x, ln, lds, twf, pc);
-          if (HAS_VEC && im.kind == ITEM_VEC) {
-            uint32_t xb[E];   // b's transform with N^-1 and the Montgomery factor folded in
+          uint32_t acc[E];    // with the last item: row A's sum
 #pragma unroll
-            for (int c = 0; c < E; ++c) xb[c] = csub(mont_lazy(x[c], pc.ninv_r2, pc.p, pc.npinv), pc.p);
-            double l1a = 0, infa = 0;
-            uint64_t unused_sq = 0;
-            load_lift<LOGN>(x, operand_ptr(ops, im.a_op, im.a_off, b, bo, N), ln, pc, first, l1a, infa, false, unused_sq, qhalf,
-                            fault);
-            wave_fwd<LOGN>(x, ln, lds, twf, pc);
-            if (first) {
-              const double p0 = l1a * infb, p1 = infa * l1b;
-              boundA += p0 < p1 ? p0 : p1;
+          for (int c = 0; c < E; ++c) acc[c] = 0;
+          if (!null_unit) {
+            const Item im = table_load(&wp->items[un.item0 + it]);
+            uint32_t x[E];      // the current transform
+            double l1b = 0, infb = 0;
+            uint64_t sumsq = 0;
+            const bool chk = first && (im.flags & (TERM_CHECK | TERM_CHECK2));
+            {
+              RZK_T0();
+              load_lift<LOGN>(x, operand_ptr(ops, im.b_op, im.b_off, b, bo, N), ln, pc, first, l1b, infb, chk, sumsq, qhalf, fault);
+              RZK_T1(t_load);
             }
-            mac_park<LOGN>(x, nullptr, xb, im.signA < 0, P4, ln, it == 0, last, pc);
-          } else {
-            if (pair && im.keyB != kNoKey) {   // row B's only product (the host puts it on the last item)
-              if (first) boundB += key_inf[im.keyB] * l1b;
+            if (chk && sumsq >= ops.norm_limit && lane == 0)
+              fail_check(flags + bo, ops.pad != 0, (im.flags & TERM_CHECK2) != 0);
+            const bool vec = HAS_VEC && im.kind == ITEM_VEC;
+            // the resident key entry of row A's product is requested before the transform, which hides its latency
+            // (N <= 1024; at N = 2048 the registers are not there and the entry is loaded after the transform)
+            constexpr bool EARLY = LOGN <= 10;
+            uint32_t kreg[E];
+            const uint4* __restrict__ kpA = reinterpret_cast<const uint4*>(key_ntt + ((size_t)im.keyA * kMaxPrimes + pi) * N);
+            if (EARLY && !vec && im.keyA != kNoKey) {
+#pragma unroll
+              for (int g = 0; g < E / 4; ++g) {
+                const uint4 kv = kpA[g * 64 + ln];
+                kreg[4 * g] = kv.x, kreg[4 * g + 1] = kv.y, kreg[4 * g + 2] = kv.z, kreg[4 * g + 3] = kv.w;
+              }
+            }
+            {
+              RZK_T0();
+              wave_fwd<LOGN>(x, ln, lds, twf, pc);
+              RZK_T1(t_fwd);
+            }
+            if (!EARLY && !vec && im.keyA != kNoKey) {
+#pragma unroll
+              for (int g = 0; g < E / 4; ++g) {
+                const uint4 kv = kpA[g * 64 + ln];
+                kreg[4 * g] = kv.x, kreg[4 * g + 1] = kv.y, kreg[4 * g + 2] = kv.z, kreg[4 * g + 3] = kv.w;
+              }
+            }
+            uint32_t xb[E];   // ITEM_VEC: b's transform with N^-1 and the Montgomery factor folded in
+            if (vec) {
+#pragma unroll
+              for (int c = 0; c < E; ++c) xb[c] = csub(mont_lazy(x[c], pc.ninv_r2, pc.p, pc.npinv), pc.p);
+              double l1a = 0, infa = 0;
+              uint64_t unused_sq = 0;
+              load_lift<LOGN>(x, operand_ptr(ops, im.a_op, im.a_off, b, bo, N), ln, pc, first, l1a, infa, false, unused_sq,
+                              qhalf, fault);
+              wave_fwd<LOGN>(x, ln, lds, twf, pc);
+              if (first) {
+                const double p0 = l1a * infb, p1 = infa * l1b;
+                boundA += p0 < p1 ? p0 : p1;
+              }
+            } else if (first) {
+              if (im.keyA != kNoKey) boundA += key_inf[im.keyA] * l1b;
+              if (pair && im.keyB != kNoKey) boundB += key_inf[im.keyB] * l1b;
+            }
+            const bool feedsA = vec || im.keyA != kNoKey;
+            const uint32_t* mulA = vec ? xb : kreg;
+            if (!last) {
+              RZK_T0();
+              if (feedsA) mac_park<LOGN, false>(x, mulA, im.signA < 0, P4, ln, it == 0, pc);
+              RZK_T1(t_mac);
+              continue;
+            }
+            RZK_T0();
+            // ---- last item: row A's sum leaves P and materialises in registers ...
+            if (fault) input_fault(ops, flags, bo, lane);
+            if (first) np = primes_for(boundA > boundB ? boundA : boundB, T);
+#pragma unroll
+            for (int c = 0; c < E; ++c) acc[c] = x[c];
+            if (feedsA) {
+              mac_park<LOGN, true>(acc, mulA, im.signA < 0, P4, ln, it == 0, pc);
+            } else {   // (an item that only feeds row B)
+#pragma unroll
+              for (int g = 0; g < E / 4; ++g) {
+                const uint4 v = P4[g * 64 + ln];
+                acc[4 * g] = v.x, acc[4 * g + 1] = v.y, acc[4 * g + 2] = v.z, acc[4 * g + 3] = v.w;
+              }
+            }
+            if (pair) {   // ... and row B's only product, from the same transform, takes its place in P
               const uint4* __restrict__ kb = reinterpret_cast<const uint4*>(key_ntt + ((size_t)im.keyB * kMaxPrimes + pi) * N);
 #pragma unroll
               for (int g = 0; g < E / 4; ++g) {
                 const uint4 kv = kb[g * 64 + ln];
                 const uint32_t ks[4] = {kv.x, kv.y, kv.z, kv.w};
+                uint32_t bs[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                  accB[4 * g + i] = im.signB < 0 ? mac_sub(0u, x[4 * g + i], ks[i], pc) : mac_add(0u, x[4 * g + i], ks[i], pc);
+                  bs[i] = im.signB < 0 ? mac_sub(0u, x[4 * g + i], ks[i], pc) : mac_add(0u, x[4 * g + i], ks[i], pc);
+                P4[g * 64 + ln] = make_uint4(bs[0], bs[1], bs[2], bs[3]);
               }
             }
-            if (im.keyA != kNoKey) {
-              if (first) boundA += key_inf[im.keyA] * l1b;
-              mac_park<LOGN>(x, reinterpret_cast<const uint4*>(key_ntt + ((size_t)im.keyA * kMaxPrimes + pi) * N), nullptr,
-                             im.signA < 0, P4, ln, it == 0, last, pc);
+            RZK_T1(t_mac);
+          }
+          // ---- transform back, fold, and after the last prime finish the row(s) of the unit
+#pragma unroll 1
+          for (uint32_t r = 0; r < (pair ? 2u : 1u); ++r) {
+            if (r == 1) {
+#pragma unroll
+              for (int g = 0; g < E / 4; ++g) {
+                const uint4 v = P4[g * 64 + ln];
+                acc[4 * g] = v.x, acc[4 * g + 1] = v.y, acc[4 * g + 2] = v.z, acc[4 * g + 3] = v.w;
+              }
+            }
+            bool done = true;
+            RZK_STEP_PRIORITY();
+            if (!null_unit) {
+              RZK_T0();
+              done = inverse_fold_global<LOGN, OPQ>(pi, np, acc, lane, lds, twf + kTableLen, pc, st + (size_t)(2 * r) * N,
+                                                    st + (size_t)(2 * r + 1) * N, T);
+              RZK_T1(t_inv);
+            }
+            if (done) {
+              RZK_T0();
+              finish_row<LOGN>(acc, prog, table_load(&prog->rows[r ? un.rowB : un.rowA]), ops, b, bo, lane, T, flags,
+                               (has_shift && r == 0) ? st_sh : nullptr);
+              RZK_T1(t_fin);
             }
           }
-        }
-        if (fault) input_fault(ops, flags, bo, lane);
-        if (first) np = primes_for(boundA > boundB ? boundA : boundB, T);
-        const uint32_t* __restrict__ twi = twf + kTableLen;
-        if (pair) {   // P is free (row A's sum sits in x): park row B while row A is transformed back
-          int ln = lane;
-          RZK_OPAQUE(ln);
-#pragma unroll
-          for (int g = 0; g < E / 4; ++g)
-            P4[g * 64 + ln] = make_uint4(accB[4 * g], accB[4 * g + 1], accB[4 * g + 2], accB[4 * g + 3]);
-        }
-        if (inverse_fold_global<LOGN, OPQ>(pi, np, x, lane, lds, twi, pc, st, st + N, T))
-          finish_row<LOGN, HAS_SHIFT>(x, prog, rowA, ops, b, bo, lane, lds, T, flags);
-        if (pair) {
-          int ln = lane;
-          RZK_OPAQUE(ln);
-#pragma unroll
-          for (int g = 0; g < E / 4; ++g) {
-            const uint4 v = P4[g * 64 + ln];
-            x[4 * g] = v.x, x[4 * g + 1] = v.y, x[4 * g + 2] = v.z, x[4 * g + 3] = v.w;
-          }
-          if (inverse_fold_global<LOGN, OPQ>(pi, np, x, lane, lds, twi, pc, st + 2 * N, st + 3 * N, T))
-            finish_row<LOGN, false>(x, prog, prog->rows[un.rowB], ops, b, bo, lane, lds, T, flags);
         }
       }
     }
   }
+#undef RZK_STEP_PRIORITY
+  if (RANKED && lane == 0) __hip_atomic_store(&ft->left[my_simd][my_slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#if RZK_STAMPS
+  if (lane == 0) {
+    const uint64_t stamp1 = __builtin_amdgcn_s_memrealtime();
+    uint32_t hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    uint32_t* o = st + 5 * N;
+    o[0] = (uint32_t)stamp0, o[1] = (uint32_t)(stamp0 >> 32), o[2] = (uint32_t)stamp1, o[3] = (uint32_t)(stamp1 >> 32);
+    o[4] = hwid, o[5] = xcc, o[6] = blockIdx.x, o[7] = wave;
+    const uint64_t cyc1 = __builtin_amdgcn_s_memtime();
+    o[8] = (uint32_t)(cyc1 - cyc0);   // shader-clock cycles of the wave's lifetime
+    o[9] = (uint32_t)t_load, o[10] = (uint32_t)t_fwd, o[11] = (uint32_t)t_mac, o[12] = (uint32_t)t_inv, o[13] = (uint32_t)t_fin;
+  }
+#endif
 }
 
 // =============================================================================================
@@ -901,49 +1121,75 @@ shift_row_kernel(const Program* __restrict__ prog, const Operands ops, const Dev
     const uint32_t rowi = task - b * nrows;
     const uint32_t bo = ops.group > 1 ? b / ops.group : b;
     const Row row = prog->rows[rowi];
-    uint32_t res[E];
-#pragma unroll
-    for (int i = 0; i < E; ++i) res[i] = 0;
     const uint32_t qhalf = T.crt.qhalf;
-    uint32_t in_bad = 0, in_mx = 0;   // canonical-input test of everything loaded outside shift_product
     bool fault = false;
-
-#pragma unroll 1
-    for (uint32_t t = 0; t < row.nterms; ++t) {
-      const Term tm = prog->terms[row.term0 + t];
-      int32_t a[E];
-      load_pairs<LOGN>(a, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), lane, qhalf, in_bad, in_mx);
-      shift_product<LOGN, true, false>(res, false, tm.sign < 0, a, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane,
-                                       slab, T, fault);
-    }
-
-#pragma unroll 1
-    for (uint32_t ai = 0; ai < row.nadds; ++ai) {
-      const AddTerm ad = prog->adds[row.add0 + ai];
-      int32_t av[E];
-      load_pairs<LOGN>(av, operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, N), lane, qhalf, in_bad, in_mx);
-      if (ad.sign >= 0) {
+    {
+      uint32_t res[E];
 #pragma unroll
-        for (int i = 0; i < E; ++i) res[i] = addq(res[i], zq_from_centered(av[i], q), q);
+      for (int i = 0; i < E; ++i) res[i] = 0;
+#pragma unroll 1
+      for (uint32_t t = 0; t < row.nterms; ++t) {
+        const Term tm = prog->terms[row.term0 + t];
+        int32_t a[E];
+        uint32_t abad = 0, amx = 0;
+        load_pairs<LOGN>(a, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), lane, qhalf, abad, amx);
+        fault = fault || canon_fail(abad, amx, qhalf);
+        shift_product<LOGN, true, false>(res, false, tm.sign < 0, a, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane,
+                                         slab, T, fault);
+      }
+      // The sums move to the (now idle) image, each lane's pairs in its own 8-byte slots, so that the additions and
+      // the store can run as a rolled loop with few registers and four 16-byte loads in flight per addition.
+      wave_sync();
+      uint2* own = reinterpret_cast<uint2*>(slab) + lane;
+#pragma unroll
+      for (int g = 0; g < S::G; ++g) own[g * 64] = make_uint2(res[2 * g], res[2 * g + 1]);
+    }
+    constexpr int GC = S::G < 4 ? S::G : 4;   // pairs per trip
+    uint32_t in_bad = 0, in_mx = 0;
+    int nz = 0;
+#pragma unroll 1
+    for (int g0 = 0; g0 < S::G; g0 += GC) {
+      uint32_t r[2 * GC];
+      const uint2* own = reinterpret_cast<const uint2*>(slab) + lane + g0 * 64;
+#pragma unroll
+      for (int g = 0; g < GC; ++g) {
+        const uint2 v = own[g * 64];
+        r[2 * g] = v.x, r[2 * g + 1] = v.y;
+      }
+#pragma unroll 1
+      for (uint32_t ai = 0; ai < row.nadds; ++ai) {
+        const AddTerm ad = prog->adds[row.add0 + ai];
+        const longlong2* __restrict__ p =
+            reinterpret_cast<const longlong2*>(operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, N)) + g0 * 64 + lane;
+        int32_t av[2 * GC];
+#pragma unroll
+        for (int g = 0; g < GC; ++g) canon_pair(p[g * 64], qhalf, in_bad, in_mx, av[2 * g], av[2 * g + 1]);
+        if (ad.sign >= 0) {
+#pragma unroll
+          for (int i = 0; i < 2 * GC; ++i) r[i] = addq(r[i], zq_from_centered(av[i], q), q);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 2 * GC; ++i) r[i] = subq(r[i], zq_from_centered(av[i], q), q);
+        }
+      }
+      if (row.mode == MODE_STORE) {
+        int4* __restrict__ dst =
+            reinterpret_cast<int4*>(const_cast<int64_t*>(operand_ptr(ops, row.out_op, row.out_off, b, bo, N))) + g0 * 64 + lane;
+#pragma unroll
+        for (int g = 0; g < GC; ++g) {
+          const int64_t c0 = center_from_zq(r[2 * g], T.crt), c1 = center_from_zq(r[2 * g + 1], T.crt);
+          dst[g * 64] = make_int4((int32_t)c0, (int32_t)(c0 >> 32), (int32_t)c1, (int32_t)(c1 >> 32));
+        }
       } else {
 #pragma unroll
-        for (int i = 0; i < E; ++i) res[i] = subq(res[i], zq_from_centered(av[i], q), q);
+        for (int i = 0; i < 2 * GC; ++i) nz |= (r[i] != 0);
       }
     }
     if (fault || canon_fail(in_bad, in_mx, qhalf)) input_fault(ops, flags, bo, lane);
-    if (row.mode == MODE_STORE) {
-      int4* __restrict__ dst = reinterpret_cast<int4*>(const_cast<int64_t*>(operand_ptr(ops, row.out_op, row.out_off, b, bo, N)));
-#pragma unroll
-      for (int g = 0; g < S::G; ++g) {
-        const int64_t c0 = center_from_zq(res[2 * g], T.crt), c1 = center_from_zq(res[2 * g + 1], T.crt);
-        dst[g * 64 + lane] = make_int4((int32_t)c0, (int32_t)(c0 >> 32), (int32_t)c1, (int32_t)(c1 >> 32));
-      }
-    } else {
-      int nz = 0;
-#pragma unroll
-      for (int i = 0; i < E; ++i) nz |= (res[i] != 0);
+    if (row.mode != MODE_STORE) {
       if (__any(nz) && lane == 0) flags[bo] = 0;
     }
+    wave_sync();   // the next task's image overwrites the slots read above
   }
 }
 
@@ -1825,43 +2071,55 @@ static inline unsigned grid_for(uint64_t tasks, int num_cus, int waves_per_block
     if (e_ != hipSuccess) return (int)e_;       \
   } while (0)
 
-size_t row_scratch_words(int logn, int num_cus) { return (size_t)num_cus * 8 * 4 * ((size_t)2 << logn); }
+size_t row_scratch_words(int logn, int num_cus) { return (size_t)num_cus * 8 * 4 * (((size_t)5 << logn) + 16); }
 
 template <int LOGN, bool HAS_VEC, bool HAS_SHIFT>
-static int launch_row_t(const LaunchCfg& cfg, const Program* d_prog, const Operands& ops,
-                        const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T,
-                        const uint32_t* d_tw, uint32_t* d_scratch, uint8_t* d_flags, uint32_t ntasks) {
+static int launch_units_t(const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, const Operands& ops,
+                          const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T, const uint32_t* d_tw,
+                          uint32_t* d_scratch, uint8_t* d_flags, uint32_t ntasks, uint32_t upt, uint32_t tpe, uint32_t wpt) {
   using G = Geo<LOGN>;
-  const size_t lds = RZK_ROW_WPB * (G::LDS_WORDS + G::N) * sizeof(uint32_t);   // transposition slab + Garner state per wave
-  const unsigned grid = grid_for(ntasks, cfg.num_cus, RZK_ROW_WPB, 8);         // <= num_cus * 8 blocks (scratch sizing)
-  hipLaunchKernelGGL((row_kernel<LOGN, HAS_VEC, HAS_SHIFT>), dim3(grid), dim3(64 * RZK_ROW_WPB), lds, (hipStream_t)cfg.stream, d_prog,
-                     ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
+  constexpr int WPB = UnitCfg<LOGN>::WPB;
+  // per wave: transposition slab + P; then the workgroup's fairness table
+  const size_t lds = WPB * (size_t)(G::LDS_WORDS + G::N) * sizeof(uint32_t) + sizeof(FairTable);
+  if (lds > 48 * 1024) {   // large dynamic LDS needs an opt-in; per device, so set before every launch (cheap, idempotent)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&unit_kernel<LOGN, HAS_VEC, HAS_SHIFT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  // scratch sizing: at most num_cus * 32 wave lines.  16-wave workgroups: one per CU at N = 1024 (133 KB of LDS), two
+  // at N = 512 — all resident, every wave walks its tasks with a grid stride.
+  const unsigned grid = WPB == 16 ? grid_for(ntasks, cfg.num_cus, 16, LOGN <= 9 ? 2 : 1) : grid_for(ntasks, cfg.num_cus, 4, 8);
+  hipLaunchKernelGGL((unit_kernel<LOGN, HAS_VEC, HAS_SHIFT>), dim3(grid), dim3(64 * WPB), lds, (hipStream_t)cfg.stream, d_prog,
+                     d_wp, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks, upt, tpe, wpt);
   RZK_LAUNCH_CHECK();
   return 0;
 }
 
-int launch_row_program(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows, bool has_vec,
-                       bool has_shift, const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf,
-                       const DevTables* T, const uint32_t* d_tw, uint32_t* d_scratch, uint8_t* d_flags,
-                       uint64_t batch) {
-  if (batch == 0 || nrows == 0) return 0;
-  if (batch * nrows >= (1ull << 32)) return -2;   // task index is 32-bit
-  const uint32_t ntasks = (uint32_t)(batch * nrows);
-#define RZK_ROW_ARGS cfg, d_prog, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks
-#define RZK_ROW_CASE(L)                                                                                        \
-  case L:                                                                                                      \
-    if (has_shift)                                                                                             \
-      return has_vec ? launch_row_t<L, true, true>(RZK_ROW_ARGS) : launch_row_t<L, false, true>(RZK_ROW_ARGS); \
-    return has_vec ? launch_row_t<L, true, false>(RZK_ROW_ARGS) : launch_row_t<L, false, false>(RZK_ROW_ARGS);
+int launch_units(int logn, const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, uint32_t nunits,
+                 uint32_t units_per_task, uint32_t work_per_entry, bool has_vec, bool has_shift, const Operands& ops,
+                 const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T, const uint32_t* d_tw,
+                 uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch) {
+  if (batch == 0 || nunits == 0) return 0;
+  if (units_per_task == 0) units_per_task = 1;
+  const uint32_t tpe = (nunits + units_per_task - 1) / units_per_task;   // tasks per batch entry
+  if (batch * tpe >= (1ull << 32)) return -2;   // task index is 32-bit
+  const uint32_t ntasks = (uint32_t)(batch * tpe);
+  const uint32_t wpt = (work_per_entry + tpe - 1) / tpe;   // transforms per task (estimate, for the progress priorities)
+#define RZK_UNIT_ARGS cfg, d_prog, d_wp, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks, units_per_task, tpe, wpt
+#define RZK_UNIT_CASE(L)                                                                                            \
+  case L:                                                                                                           \
+    if (has_shift)                                                                                                  \
+      return has_vec ? launch_units_t<L, true, true>(RZK_UNIT_ARGS) : launch_units_t<L, false, true>(RZK_UNIT_ARGS); \
+    return has_vec ? launch_units_t<L, true, false>(RZK_UNIT_ARGS) : launch_units_t<L, false, false>(RZK_UNIT_ARGS);
   switch (logn) {
-    RZK_ROW_CASE(9)
-    RZK_ROW_CASE(10)
-    case 11:   // shift terms are not built for N = 2048 (rzk_api.cpp, shift_ok)
+    RZK_UNIT_CASE(9)
+    RZK_UNIT_CASE(10)
+    case 11:   // rotation terms are not built for N = 2048 (rzk_api.cpp, shift_ok)
       if (has_shift) return -1;
-      return has_vec ? launch_row_t<11, true, false>(RZK_ROW_ARGS) : launch_row_t<11, false, false>(RZK_ROW_ARGS);
+      return has_vec ? launch_units_t<11, true, false>(RZK_UNIT_ARGS) : launch_units_t<11, false, false>(RZK_UNIT_ARGS);
   }
-#undef RZK_ROW_ARGS
-#undef RZK_ROW_CASE
+#undef RZK_UNIT_ARGS
+#undef RZK_UNIT_CASE
   return -1;
 }
 

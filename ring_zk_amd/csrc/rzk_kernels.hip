@@ -832,9 +832,12 @@ __device__ __forceinline__ void finish_row(uint32_t* u, const Program* __restric
 
 // Wavefronts per workgroup: 16 (the whole CU: exact fairness among SIMD mates, see set_rank_priority) up to N = 1024;
 // 4 at N = 2048, where 16 slabs do not fit the CU's LDS.
+#ifndef RZK_UNIT_WPB
+#define RZK_UNIT_WPB 4   // (16-wave workgroups with rank priorities measured slower for the verify rows: 90 vs 81 us)
+#endif
 template <int LOGN>
 struct UnitCfg {
-  static constexpr int WPB = LOGN <= 10 ? 16 : 4;
+  static constexpr int WPB = LOGN <= 10 ? RZK_UNIT_WPB : 4;
 };
 
 template <int LOGN, bool HAS_VEC, bool HAS_SHIFT>

@@ -7,17 +7,23 @@ HBM GB/s of the kernels against the chip's roofline.
 
 A "step" is one pass of the hot path over one batch: rzk_open_commit_batch_dev,
 rzk_open_response_batch_dev, rzk_open_verify_batch_dev on inputs already resident in HBM.  The
-challenge d is pre-sampled like every other random input (the reference samples it with the host RNG
-and does no ring arithmetic in generate_challenge — src/prove/open.rs:143-158).
+random inputs (r, y and the challenge d) are pre-sampled like the data itself: the reference draws them with the
+host RNG and does no ring arithmetic in generate_challenge (src/prove/open.rs:143-158), so no
+sampler is inside the timed region (config.inputs says so; the device samplers are timed by tools/bench_phases.py).
 
   python bench.py --gpus N --steps K --warmup W
 N > 1 is launched by the driver through torch.distributed.run (one rank per GPU, RCCL only for the
-barrier / result reduction: proofs are independent, the batch is simply split, weak scaling).
+barrier / key broadcast / result reduction: proofs are independent, the batch is simply split, weak scaling).
+
+Other BASELINE configurations: --workload linear|sum --N --shape n,k,l --summands V --batch B [--chunk C].
+With --chunk the batch is processed in sub-batches of C proofs whose inputs are re-drawn by the device samplers for
+every chunk INSIDE the timed region (config 5: 4096 proofs x ~45 MB of live data do not fit in HBM at once).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -26,7 +32,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+BUTTERFLY_PEAK = 4.7e12      # measured chip-wide rate of the 32-bit Montgomery butterfly at 4 waves per SIMD
+                             # (tools/microbench/valu_rates.cpp, profiles/r01_valu_rates.txt): the VALU ceiling
 
 
 def parse():
@@ -36,19 +44,72 @@ def parse():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--N", type=int, default=1024)
     ap.add_argument("--batch", type=int, default=4096, help="proofs per GPU and step")
+    ap.add_argument("--chunk", type=int, default=0, help="process the batch in sub-batches of this many proofs, "
+                    "inputs re-drawn per chunk by the device samplers inside the timed region (0 = whole batch resident)")
     ap.add_argument("--workload", choices=["open", "linear", "sum"], default="open",
                     help="open = BASELINE metric config; linear / sum = the other BASELINE configs")
     ap.add_argument("--shape", type=str, default="1,3,1", help="n,k,l")
     ap.add_argument("--summands", type=int, default=8, help="V for --workload sum")
-    ap.add_argument("--ramp", type=int, default=100,
+    ap.add_argument("--ramp", type=int, default=-1,
                     help="untimed steps run once before the warmup: the GPU needs ~20 ms of load to reach steady "
-                         "clocks (measured: 337 us/step right after start-up vs 288 us/step once warm)")
+                         "clocks (measured: 337 us/step right after start-up vs 288 us/step once warm); -1 = 100 for "
+                         "the open workload, 2 otherwise")
+    ap.add_argument("--broadcast-key", type=int, default=1,
+                    help="N > 1: rank 0 generates the key and broadcasts the [a1;a2] slab (RCCL) instead of every rank "
+                         "regenerating it from the seed")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=40.0, help="target length of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target length of the CPU baseline sample")
     return ap.parse_args()
 
 
-def cpu_baseline(N, n, k, l, seconds):
+# ---- accounting ---------------------------------------------------------------------------------------------------
+def cycle_polys(workload, n, k, l, V):
+    """Polynomials a cycle moves at the boundary, key resident: everything a phase takes in or hands out."""
+    if workload == "open":      # 7+3, 7+3, 6 = 26 at (1,3,1)
+        return {"commit": (l + 2 * k) + (2 * n + l), "response": (2 * k + 1) + k, "verify": k + n + l + 1}   # z, t, c1, d
+    if workload == "linear":
+        return {"commit": (1 + l + 4 * k) + (4 * n + 3 * l), "response": (4 * k + 1) + 2 * k,
+                "verify": 2 * k + 2 * (n + l) + 1 + 2 * n + l + 1}
+    return {"commit": (V + V * l + 2 * V * k + 2 * k) + ((V + 1) * (n + l) + (V + 1) * n + l),
+            "response": (2 * V * k + 2 * k + 1) + (V + 1) * k,
+            "verify": (V + 1) * k + (V + 1) * (n + l) + V + (V + 1) * n + l + 1}
+
+
+def ring_multiplies(workload, n, k, l, V):
+    """Ring multiplies of the reference per cycle (SURVEY §3.6: Mat::dot multiplies identity / zero blocks too)."""
+    if workload == "open":
+        return (2 * n + l) * k + k + (n * k + n)
+    if workload == "linear":
+        return (2 * l + 4 * n * k + 4 * l * k) + 2 * k + (2 * n * k + 2 * n + 2 * l * k + 3 * l)
+    return (2 * V * l + (V + 1) * k * (2 * n + 2 * l)) + (V + 1) * k + ((V + 1) * (n * k + n + l * k) + 2 * V * l + l)
+
+
+def min_transform_units(workload, n, k, l, V, rot):
+    """Transform units (one length-N transform over one 30-bit prime) a cycle needs at least with this design: every
+    distinct operand transformed once per prime and program, every output row transformed back once per prime.
+    Key products with ternary / Gaussian operands need 2 primes, products of two full-range polynomials 3, the
+    response rows and the challenge products of the verifiers none when they run as rotations (rot: N <= 1024).
+    a1' has ca = k-n random columns, a2' has cb = k-n-l (a subset of the same operands)."""
+    ca, cb = k - n, k - n - l
+    commit_one = 2 * (ca + n + l) + 2 * (ca + n)           # c = [a1;a2].r + [0;x] and t = a1.y
+    rel_one = 2 * (ca + n) + (0 if rot else 2 * (n + 1))   # a1.z - c1 (.) d - t == 0
+    resp_one = 0 if rot else 1 + 2 * k                     # z = y + r (.) d  (one prime)
+    a2_one = 2 * (cb + l)                                  # a2 . v as a program of its own
+    if workload == "open":
+        return commit_one + resp_one + rel_one
+    if workload == "linear":
+        commit = 3 * (2 * l + 1) + 2 * commit_one + 2 * l + 3 * (2 * l + 1 + cb)   # gx; two commits with t, t'; a2.y; u
+        verify = 2 * rel_one + 2 * l + 3 * (2 * l + 1) + 3 * (2 * l + 1 + cb) + (0 if rot else 3 * (l + 1))
+        return commit + 2 * resp_one + verify
+    vec = 3 * (V * l + V + l)                              # sum_i x_i (.) g_i over l rows
+    vec_key = 3 * (V * l + V + cb + l)                     # sum_i w_i (.) g_i - a2 . v'
+    commit = vec + (V + 1) * commit_one + V * a2_one + vec_key
+    verify = (V + 1) * rel_one + V * a2_one + vec + vec_key + (0 if rot else 3 * (l + 1))
+    return commit + (V + 1) * resp_one + verify
+
+
+# ---- CPU baseline ---------------------------------------------------------------------------------------------------
+def cpu_baseline(workload, N, n, k, l, V, seconds):
     """CPU restatement (oracle, schoolbook multiply, literal Mat::dot) timed on the host cores."""
     import numpy as np
 
@@ -59,32 +120,62 @@ def cpu_baseline(N, n, k, l, seconds):
     threads = O.hw_threads()
     rng = np.random.default_rng(99)
     A = synth.key(rng, N, n, k, l)
+    if workload == "open":
+        def sample(B):
+            x = synth.uniform(rng, (B, l, N))
+            r = synth.small(rng, (B, k, N))
+            y = synth.gauss(rng, (B, k, N), P.sigma)
+            d = synth.challenge(rng, (B,), N, P.kappa)
+            t0 = time.perf_counter()
+            acc = O.open_cycle_batch(P, A, x, r, y, d, threads)
+            dt = time.perf_counter() - t0
+            assert acc == B, f"CPU baseline: {acc}/{B} proofs accepted"
+            return dt
 
-    def sample(B):
-        x = synth.uniform(rng, (B, l, N))
-        r = synth.small(rng, (B, k, N))
-        y = synth.gauss(rng, (B, k, N), P.sigma)
-        d = synth.challenge(rng, (B,), N, P.kappa)
-        t0 = time.perf_counter()
-        acc = O.open_cycle_batch(P, A, x, r, y, d, threads)
-        dt = time.perf_counter() - t0
-        assert acc == B, f"CPU baseline: {acc}/{B} proofs accepted"
-        return dt
+        probe = max(threads, 8)
+        dt = sample(probe)
+        rate = probe / dt
+        B = int(max(probe, min(rate * seconds, 65536)))
+        B -= B % threads or 0
+        B = max(B, threads)
+        dt = sample(B)
+        how = "OpenMP over proofs"
+    else:
+        # Linear / Sum: single proofs one after the other; at N >= 1024 the oracle spreads every ring multiply over the
+        # host threads (rzko_poly_mul), below that it runs on one core
+        def one():
+            g = synth.uniform(rng, (max(V, 1), N))
+            xs = synth.uniform(rng, (max(V, 1), l, N))
+            rs, rp = synth.small(rng, (max(V, 1), k, N)), synth.small(rng, (k, N))
+            ys, yp = synth.gauss(rng, (max(V, 1), k, N), P.sigma), synth.gauss(rng, (k, N), P.sigma)
+            d = synth.challenge(rng, (1,), N, P.kappa)[0]
+            t0 = time.perf_counter()
+            if workload == "linear":
+                c, cp, t, tp, u, ok = O.linear_commit(P, A, g[0], xs[0], rs[0], rp, ys[0], yp)
+                z, zp = O.linear_response(P, ys[0], yp, rs[0], rp, d)
+                acc = O.linear_verify(P, A, z, zp, c, cp, g[0], t, tp, u, d)
+            else:
+                cs, cp, ts, tp, u, ok = O.sum_commit(P, A, g, xs, rs, rp, ys, yp)
+                zs, zp = O.sum_response(P, ys, yp, rs, rp, d)
+                acc = O.sum_verify(P, A, zs, zp, cs, cp, g, ts, tp, u, d)
+            dt = time.perf_counter() - t0
+            assert acc == 1, "CPU baseline: proof rejected"
+            return dt
 
-    probe = max(threads, 8)
-    dt = sample(probe)
-    rate = probe / dt
-    B = int(max(probe, min(rate * seconds, 65536)))
-    B -= B % threads or 0
-    B = max(B, threads)
-    dt = sample(B)
+        dt1 = one()
+        B = int(max(1, min(seconds / max(dt1, 1e-6), 4096)))
+        dt = sum(one() for _ in range(B))
+        how = "proofs one after the other, ring multiplies spread over the host threads" if N >= 1024 else "one core"
+        if N < 1024:
+            threads = 1
     return {
         "value": B / dt,
         "unit": "proofs/s",
         "cores": threads,
         "kind": "port",
-        "sample": f"{B} OpenProof cycles (commit+response+verify), N={N}, (n,k,l)=({n},{k},{l}), "
-                  f"schoolbook CPU restatement (oracle/rzk_oracle.c), OpenMP over proofs, {dt:.1f} s",
+        "sample": f"{B} {workload.capitalize()}Proof cycles (commit+response+verify), N={N}, (n,k,l)=({n},{k},{l})"
+                  + (f", V={V}" if workload == "sum" else "")
+                  + f", schoolbook CPU restatement (oracle/rzk_oracle.c), {how}, {dt:.1f} s",
     }
 
 
@@ -119,90 +210,94 @@ def main():
 
     N = args.N
     n, k, l = (int(v) for v in args.shape.split(","))
-    V = args.summands
+    V = args.summands if args.workload == "sum" else 1
     B = args.batch
+    chunk = args.chunk if 0 < args.chunk < B else 0
+    Bc = chunk or B                      # proofs resident at a time
+    nchunks = (B + Bc - 1) // Bc
+    assert B % Bc == 0, "--chunk must divide --batch"
+    ramp = args.ramp if args.ramp >= 0 else (100 if args.workload == "open" and not chunk else 2)
     dev = torch.device("cuda", dev_index)
     red_dev = dev if backend == "nccl" else torch.device("cpu")   # where the result reduction runs
     ctx = Context(N, n, k, l, device=dev_index)
     sig = ctx.sigma
 
-    # ---- synthetic inputs, generated directly in HBM; same key on every rank, different proofs per rank
+    # ---- commitment key: same on every rank.  Rank 0 draws it and broadcasts the dense [a1;a2] slab (48 KiB at
+    # (1,3,1) N=1024, 4.25 MiB at config 5: SURVEY §8e); --broadcast-key 0 regenerates it from the seed per rank.
     gk = torch.Generator(device=dev)
     gk.manual_seed(1234)
     A = synth.t_key(gk, N, n, k, l, dev)
+    if world > 1 and args.broadcast_key:
+        A = shard.broadcast_key(dist, A if rank == 0 else torch.zeros_like(A), red_dev)
     ctx.load_key(A)
     # per-proof inputs from the library's device-side samplers (counter-based, seed recorded in the output):
     # the reference's distributions: x, g uniform over Z_q; r uniform in [-b, b]; y = (i64) N(0, sigma);
     # d with kappa coefficients +-1
     seed = 1000 + rank
     half = (ctx.q - 1) // 2
-    sid = iter(range(64))
 
-    def uni(*lead):
-        return ctx.sample_uniform(seed, next(sid), half, lead)
+    def draw(chunk_index):
+        sid = iter(range(64 * chunk_index, 64 * chunk_index + 64))
+        uni = lambda *lead: ctx.sample_uniform(seed, next(sid), half, lead)
+        small = lambda *lead: ctx.sample_uniform(seed, next(sid), ctx.b, lead)
+        gauss = lambda *lead: ctx.sample_gauss(seed, next(sid), float(sig), lead)
+        d = ctx.sample_challenge(seed, next(sid), (Bc,))
+        if args.workload == "open":
+            return dict(d=d, x=uni(Bc, l), r=small(Bc, k), y=gauss(Bc, k))
+        if args.workload == "linear":
+            return dict(d=d, g=uni(Bc), x=uni(Bc, l), r=small(Bc, k), rp=small(Bc, k), y=gauss(Bc, k), yp=gauss(Bc, k))
+        return dict(d=d, gs=uni(Bc, V), xs=uni(Bc, V, l), rs=small(Bc, V, k), rp=small(Bc, k), ys=gauss(Bc, V, k),
+                    yp=gauss(Bc, k))
 
-    def small(*lead):
-        return ctx.sample_uniform(seed, next(sid), ctx.b, lead)
-
-    def gauss(*lead):
-        return ctx.sample_gauss(seed, next(sid), float(sig), lead)
-
-    d = ctx.sample_challenge(seed, next(sid), (B,))
-    if args.workload == "open":
-        x = uni(B, l)
-        r = small(B, k)
-        y = gauss(B, k)
-        cycle_polys = (l + 2 * k) + (2 * n + l) + (2 * k + 1) + k + (k + 2 * n + 1)   # 26 at (1,3,1): SURVEY §8d
-        row_launches = 3
-
-        def phases():
-            c, t, ok = ctx.open_commit(x, r, y)
+    def phases(I):
+        if args.workload == "open":
+            c, t, ok = ctx.open_commit(I["x"], I["r"], I["y"])
             yield "commit"
-            z = ctx.open_response(y, r, d)
+            z = ctx.open_response(I["y"], I["r"], I["d"])
             yield "response"
-            acc = ctx.open_verify(z, t, c, d)
+            acc = ctx.open_verify(z, t, c, I["d"])
             yield "verify"
-            phases.result = (ok, acc)
-    elif args.workload == "linear":
-        gp = uni(B)
-        x = uni(B, l)
-        r, rp = small(B, k), small(B, k)
-        y, yp = gauss(B, k), gauss(B, k)
-        cycle_polys = ((1 + l + 4 * k) + (4 * n + 3 * l)) + ((4 * k + 1) + 2 * k) + (2 * k + 2 * (n + l) + 1 + 2 * n + l + 1)
-        row_launches = 3 + 1 + 2
-
-        def phases():
-            c, cp, t, tp, u, ok = ctx.linear_commit(gp, x, r, rp, y, yp)
+        elif args.workload == "linear":
+            c, cp, t, tp, u, ok = ctx.linear_commit(I["g"], I["x"], I["r"], I["rp"], I["y"], I["yp"])
             yield "commit"
-            z, zp = ctx.linear_response(y, yp, r, rp, d)
+            z, zp = ctx.linear_response(I["y"], I["yp"], I["r"], I["rp"], I["d"])
             yield "response"
-            acc = ctx.linear_verify(z, zp, c, cp, gp, t, tp, u, d)
+            acc = ctx.linear_verify(z, zp, c, cp, I["g"], t, tp, u, I["d"])
             yield "verify"
-            phases.result = ((ok == 3).to(torch.uint8), acc)
-    else:
-        gs = uni(B, V)
-        xs = uni(B, V, l)
-        rs, rp = small(B, V, k), small(B, k)
-        ys, yp = gauss(B, V, k), gauss(B, k)
-        cycle_polys = ((V + V * l + 2 * V * k + 2 * k) + ((V + 1) * (n + l) + (V + 1) * n + l)) + \
-                      ((2 * V * k + 2 * k + 1) + (V + 1) * k) + \
-                      ((V + 1) * k + (V + 1) * (n + l) + V + (V + 1) * n + l + 1)
-        row_launches = 5 + 2 + 5
-
-        def phases():
-            cs, cp, ts, tp, u, ok = ctx.sum_commit(gs, xs, rs, rp, ys, yp)
+            ok = (ok == 3).to(torch.uint8)
+        else:
+            cs, cp, ts, tp, u, ok = ctx.sum_commit(I["gs"], I["xs"], I["rs"], I["rp"], I["ys"], I["yp"])
             yield "commit"
-            zs, zp = ctx.sum_response(ys, yp, rs, rp, d)
+            zs, zp = ctx.sum_response(I["ys"], I["yp"], I["rs"], I["rp"], I["d"])
             yield "response"
-            acc = ctx.sum_verify(zs, zp, cs, cp, gs, ts, tp, u, d)
+            acc = ctx.sum_verify(zs, zp, cs, cp, I["gs"], ts, tp, u, I["d"])
             yield "verify"
-            phases.result = (ok, acc)
+        phases.result = (ok, acc)
+
+    resident = None if chunk else draw(0)
     torch.cuda.synchronize()
+    accepted = [0, 0]   # accept / commit-ok counts of the last step
 
-    def step():
-        for _ in phases():
-            pass
-        return phases.result
+    def step(marks=None, count=False):
+        """One pass over the batch.  marks: list collecting launch-count marks per phase (profiled steps);
+        count: also add up the verdict flags of every chunk (done for the last timed step only: two small torch
+        reductions per chunk that are not part of the path)."""
+        tot_ok = tot_acc = None
+        for ci in range(nchunks):
+            I = resident if resident is not None else draw(ci)
+            if marks is not None:
+                m = [ctx.prof_count()]
+                for _name in phases(I):
+                    m.append(ctx.prof_count())
+                marks.append(m)
+            else:
+                for _name in phases(I):
+                    pass
+            if count:
+                ok, acc = phases.result
+                tot_ok = ok.sum() if tot_ok is None else tot_ok + ok.sum()
+                tot_acc = acc.sum() if tot_acc is None else tot_acc + acc.sum()
+        return tot_ok, tot_acc
 
     def barrier():
         shard.barrier(dist, dev)
@@ -210,96 +305,132 @@ def main():
     # HIP events (created without the system-scope fence) bracket the row-kernel launches of every 8th timed
     # step, on the stream the kernels run on; they are read back after the timed region.  Bracketing every
     # launch costs 4 % of throughput (a ~5 us bubble per event pair) without changing the kernel durations
-    # (135 / 72 / 82 us either way, equal to rocprofv3's); every 8th step keeps that below 1 %.
+    # (equal to rocprofv3's either way); every 8th step keeps that below 1 %.
     # RZK_BENCH_PROF=0 times the loop without any event and profiles in a separate pass.
     prof_live = rank == 0 and os.environ.get("RZK_BENCH_PROF", "1") != "0"
     prof_every = 8
-    for _ in range(args.ramp + args.warmup):
-        ok, acc = step()
+    for _ in range(ramp + args.warmup):
+        step()
     barrier()
-    marks = []   # (launch count before the step, after commit, after response, after verify)
+    marks = []   # (launch count before the chunk, after commit, after response, after verify)
     if prof_live:
         ctx.prof_reset()
     t0 = time.perf_counter()
     for i in range(args.steps):
+        final = i + 1 == args.steps
         if prof_live and i % prof_every == 0:
             ctx.prof_enable(True)
-            m = [ctx.prof_count()]
-            for _name in phases():
-                m.append(ctx.prof_count())
-            marks.append(m)
+            res = step(marks, count=final)
             ctx.prof_enable(False)
-            ok, acc = phases.result
         else:
-            ok, acc = step()
+            res = step(count=final)
+        if final:
+            ok_s, acc_s = res
     barrier()
     elapsed = time.perf_counter() - t0
 
-    accepted = int(acc.sum().item())
-    ok_cnt = int(ok.sum().item())
+    accepted, ok_cnt = int(acc_s.item()), int(ok_s.item())
     assert accepted == B and ok_cnt == B, f"rank {rank}: {accepted}/{B} accepted, {ok_cnt}/{B} commit-ok"
 
-    elapsed, tot_acc = shard.reduce_result(dist, elapsed, accepted, red_dev)
+    elapsed, tot_acc, per_rank = shard.reduce_result(dist, elapsed, accepted, red_dev, gather=True)
     proofs = B * world * args.steps
     value = proofs / elapsed
 
     roofline = None
     ntt = None
+    units = None
     if rank == 0:
         if not prof_live:   # same measurement in a separate pass
             ctx.prof_enable(True)
             ctx.prof_reset()
             for _ in range(max(3, min(args.steps, 10))):
-                m = [ctx.prof_count()]
-                for _name in phases():
-                    m.append(ctx.prof_count())
-                marks.append(m)
+                step(marks)
         durs = ctx.prof_read_all()
         ctx.prof_enable(False)
         launches = len(durs)
-        avg_us = sum(durs) / max(launches, 1)
-        # per phase: sum of the durations of its row-kernel launches, averaged over the steps
-        phase_us = {name: sum(sum(durs[m[j]:m[j + 1]]) for m in marks) / max(len(marks), 1)
-                    for j, name in enumerate(("commit", "response", "verify"))}
-        # algorithmic bytes of one cycle at the boundary, key resident: every polynomial a
-        # phase takes in or hands out, 8*N bytes each (Open at (1,3,1): 7+3, 7+3, 6 = 26 polynomials)
-        cycle_bytes = cycle_polys * 8 * N * B
-        per_launch = cycle_bytes / float(row_launches)
-        achieved = per_launch / (avg_us * 1e-6) / 1e9
-        traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_row_kernel.json")
-        if os.path.exists(pmc_path):
+        nprof = max(len(marks), 1)
+        # per phase: the durations of its row-program launches, averaged over the profiled chunks
+        names = ("commit", "response", "verify")
+        phase_launch_us = {name: [0.0] * (marks[0][j + 1] - marks[0][j]) for j, name in enumerate(names)} if marks else {}
+        for m in marks:
+            for j, name in enumerate(names):
+                for li, dur in enumerate(durs[m[j]:m[j + 1]]):
+                    phase_launch_us[name][li] += dur / nprof
+        phase_us = {name: sum(v) for name, v in phase_launch_us.items()}
+        polys = cycle_polys(args.workload, n, k, l, V)
+        # algorithmic bytes at the boundary, key resident: every polynomial a phase takes in or hands
+        # out, 8*N bytes each (Open at (1,3,1): 10 + 10 + 6 = 26 polynomials)
+        phase_bytes = {name: polys[name] * 8 * N * Bc for name in names}
+        cycle_bytes = sum(phase_bytes.values())
+        cycle_us = sum(phase_us.values())
+        # the dominant kernel = the single launch with the largest duration; its own bytes and duration give `frac`.
+        # For the Open cycle every phase is one launch, so its bytes are the phase's; for Linear / Sum a phase is
+        # several launches and the phase's bytes / phase's time are reported for the phase that holds the launch.
+        dom_phase = max(names, key=lambda nm: max(phase_launch_us[nm]) if phase_launch_us.get(nm) else 0.0)
+        dom_us = max(phase_launch_us[dom_phase])
+        single = len(phase_launch_us[dom_phase]) == 1
+        dom_bytes = phase_bytes[dom_phase]
+        dom_time = dom_us if single else phase_us[dom_phase]
+        achieved = dom_bytes / (dom_time * 1e-6) / 1e9
+        kernel_names = {"open": {"commit": "unit_kernel<log2 N, false, false> (commit rows c, t: pair unit + single unit per proof)",
+                                 "response": "shift_row_kernel<log2 N> (z = y + r (.) d as rotations)",
+                                 "verify": "unit_kernel<log2 N, false, true> (a1.z - c1 (.) d - t == 0, rotation term)"}}
+        traffic, traffic_src = None, None
+        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        if args.workload == "open" and N == 1024 and os.path.exists(pmc_path):
             try:
-                traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc_path))
+                traffic = pj.get("hbm_bytes_per_launch", {}).get(dom_phase)
+                traffic_src = "imported from profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
+                              "this same command, corrected as the guide prescribes; not measured in this run)"
             except Exception:
                 traffic = None
         roofline = {
-            "kernel": f"row-program kernels at log2 N={N.bit_length() - 1} (row_kernel: commit / verify rows; "
-                      "shift_row_kernel: response rows), one launch per phase",
+            "kernel": kernel_names.get(args.workload, {}).get(dom_phase, f"{dom_phase} phase ({len(phase_launch_us[dom_phase])} row-program launches)")
+                      .replace("log2 N", str(N.bit_length() - 1)),
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "avg_launch_us": avg_us,
+            "traffic_source": traffic_src,
+            "avg_launch_us": dom_time,
+            "algorithmic_bytes_per_launch": dom_bytes,
+            "scope": "the dominant kernel's own launch" if single else f"all launches of the {dom_phase} phase",
             "phase_us": phase_us,
+            "phase_frac": {nm: (phase_bytes[nm] / (phase_us[nm] * 1e-6) / 1e9) / HBM_PEAK_GBS if phase_us.get(nm) else None
+                           for nm in names},
+            "cycle": {"us": cycle_us, "algorithmic_bytes": cycle_bytes,
+                      "achieved": cycle_bytes / (cycle_us * 1e-6) / 1e9 if cycle_us else None,
+                      "frac": cycle_bytes / (cycle_us * 1e-6) / 1e9 / HBM_PEAK_GBS if cycle_us else None},
             "launches_timed": int(launches),
-            "algorithmic_bytes_per_launch": per_launch,
         }
+        rot = N <= 1024
+        upp = min_transform_units(args.workload, n, k, l, V, rot)
+        bpu = (N // 2) * (N.bit_length() - 1)
+        brate = upp * bpu * value / max(world, 1)
+        units = {"ring_multiplies_per_proof_reference": ring_multiplies(args.workload, n, k, l, V),
+                 "transform_units_per_proof_min": upp, "butterflies_per_unit": bpu,
+                 "butterflies_per_s_per_gpu": brate, "butterfly_peak": BUTTERFLY_PEAK,
+                 "frac_of_butterfly_peak": brate / BUTTERFLY_PEAK,
+                 "note": "minimum transform units of the design (operands once per prime and program, rows once per prime; "
+                         "rotations instead of transforms for challenge products at N <= 1024) x (N/2) log2 N butterflies, "
+                         "against the measured chip-wide butterfly rate (integer-VALU ceiling)"}
         # stand-alone batched forward NTT (one residue polynomial = 2*N*4 algorithmic bytes)
         # 65536 x 4 KiB in + the same out = 512 MiB per launch: beyond the 256 MiB Infinity Cache
-        cnt = 16 * 4096
-        xin = torch.randint(0, ctx.ntt_prime(0), (cnt, N), dtype=torch.int32, device=dev)
-        xout = torch.empty_like(xin)
-        ntt_us = ctx.bench_ntt_forward(0, xin, xout, 20)
-        ntt_gbs = cnt * 2 * N * 4 / (ntt_us * 1e-6) / 1e9
-        ntt = {"kernel": "ntt_fwd_kernel<10>", "polys": cnt, "avg_launch_us": ntt_us, "achieved": ntt_gbs,
-               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ntt_gbs / HBM_PEAK_GBS}
+        if N >= 512:
+            cnt = 16 * 4096
+            xin = torch.randint(0, ctx.ntt_prime(0), (cnt, N), dtype=torch.int32, device=dev)
+            xout = torch.empty_like(xin)
+            ntt_us = ctx.bench_ntt_forward(0, xin, xout, 20)
+            ntt_gbs = cnt * 2 * N * 4 / (ntt_us * 1e-6) / 1e9
+            ntt = {"kernel": f"ntt_fwd_kernel<{N.bit_length() - 1}>", "polys": cnt, "avg_launch_us": ntt_us, "achieved": ntt_gbs,
+                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ntt_gbs / HBM_PEAK_GBS}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "open":
-        cpu = cpu_baseline(N, n, k, l, args.cpu_seconds)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.workload, N, n, k, l, V, args.cpu_seconds)
 
     if rank == 0:
         out = {
@@ -317,16 +448,22 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload.capitalize()}Proof cycle, N={N}, (n,k,l)=({n},{k},{l}), kappa=36, "
-                            + (f"V={V} summands, " if args.workload == "sum" else "") + f"batch={B} proofs per GPU",
+                            + (f"V={V} summands, " if args.workload == "sum" else "") + f"batch={B} proofs per GPU"
+                            + (f", processed in {nchunks} chunks of {Bc} proofs" if chunk else ""),
                 "arithmetic": "u32 residues of up to three 30-bit NTT primes, exact CRT to the centred residue mod q; "
-                              "int64 coefficients at the boundary",
+                              "int64 coefficients at the boundary, every one tested for the centred range while it is loaded",
                 "inputs": f"device-side samplers (Philox4x32-10), seed {1000}+rank: x uniform over Z_q, r in [-b,b], "
-                          "y=(i64)N(0,sigma), d with kappa +-1; resident in HBM before the timed region",
-                "challenge": "pre-sampled (sampling is outside the path)",
-                "parallelism": f"batch split over {world} GPU(s), no data-path collective",
+                          "y=(i64)N(0,sigma), d with kappa +-1; "
+                          + ("re-drawn per chunk INSIDE the timed region (the whole batch does not fit in HBM)" if chunk else
+                             "pre-sampled and resident in HBM before the timed region: no sampler (r, y, challenge d) is timed"),
+                "challenge": "pre-sampled like every random input (generate_challenge does no ring arithmetic, open.rs:143-158)",
+                "parallelism": f"batch split over {world} GPU(s), no data-path collective; key "
+                               + ("broadcast from rank 0" if world > 1 and args.broadcast_key else "generated from the same seed on every rank"),
                 "accepted": tot_acc,
+                "accepted_per_rank": per_rank,
             },
             "roofline": roofline,
+            "units": units,
             "ntt_roofline": ntt,
             "cpu_baseline": cpu,
         }

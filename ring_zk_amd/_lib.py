@@ -96,7 +96,12 @@ def lib() -> C.CDLL:
             pass
         L = C.CDLL(SO)
         for name, (res, args) in SIGNATURES.items():
-            f = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            try:
+                f = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            except AttributeError:
+                if "RZK_LIB" in os.environ:   # tuning / comparison variants (tools/) may predate a symbol
+                    continue
+                raise
             f.restype = res
             f.argtypes = args
         _lib = L

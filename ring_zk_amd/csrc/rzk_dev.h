@@ -35,7 +35,7 @@ struct DevTables {
 #if defined(__HIPCC__)
 template <class Tp>
 __device__ __forceinline__ Tp table_load(const Tp* p) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RZK_NO_TABLE_SLOAD)
   typedef const Tp __attribute__((address_space(4))) * cptr_t;
   return *reinterpret_cast<cptr_t>(reinterpret_cast<uintptr_t>(p));
 #else

@@ -651,21 +651,34 @@ __device__ __forceinline__ void set_rank_priority(FairTable* ft, uint32_t simd, 
 template <int LOGN, bool to_regs>
 __device__ __forceinline__ void mac_park(uint32_t* x, const uint32_t* mul, bool minus, uint4* P4, int lane, bool init,
                                          const PrimeConsts& pc) {
+  // (the sign is tested once, outside the element loops: a per-element select of mac_add / mac_sub made the
+  // compiler branch per coefficient; `mul` must be a register array of the caller, never a pointer chosen at run time,
+  // or both candidates end up in scratch memory)
   constexpr int E = Geo<LOGN>::E;
+  uint32_t as[E];
+  if (init) {
 #pragma unroll
-  for (int g = 0; g < E / 4; ++g) {
-    uint4 a = make_uint4(0, 0, 0, 0);
-    if (!init) a = P4[g * 64 + lane];
-    uint32_t as[4] = {a.x, a.y, a.z, a.w};
+    for (int c = 0; c < E; ++c) as[c] = 0;
+  } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      as[i] = minus ? mac_sub(as[i], x[4 * g + i], mul[4 * g + i], pc) : mac_add(as[i], x[4 * g + i], mul[4 * g + i], pc);
-    if (to_regs) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) x[4 * g + i] = as[i];
-    } else {
-      P4[g * 64 + lane] = make_uint4(as[0], as[1], as[2], as[3]);
+    for (int g = 0; g < E / 4; ++g) {
+      const uint4 a = P4[g * 64 + lane];
+      as[4 * g] = a.x, as[4 * g + 1] = a.y, as[4 * g + 2] = a.z, as[4 * g + 3] = a.w;
     }
+  }
+  if (minus) {
+#pragma unroll
+    for (int c = 0; c < E; ++c) as[c] = mac_sub(as[c], x[c], mul[c], pc);
+  } else {
+#pragma unroll
+    for (int c = 0; c < E; ++c) as[c] = mac_add(as[c], x[c], mul[c], pc);
+  }
+  if (to_regs) {
+#pragma unroll
+    for (int c = 0; c < E; ++c) x[c] = as[c];
+  } else {
+#pragma unroll
+    for (int g = 0; g < E / 4; ++g) P4[g * 64 + lane] = make_uint4(as[4 * g], as[4 * g + 1], as[4 * g + 2], as[4 * g + 3]);
   }
 }
 
@@ -841,7 +854,7 @@ struct UnitCfg {
 };
 
 template <int LOGN, bool HAS_VEC, bool HAS_SHIFT>
-__global__ void __launch_bounds__(64 * UnitCfg<LOGN>::WPB)
+__global__ void __launch_bounds__(64 * UnitCfg<LOGN>::WPB, (LOGN <= 10 ? 4 : 1))   // N <= 1024: LDS allows 4 waves per SIMD
 unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp, const Operands ops,
             const uint32_t* __restrict__ key_ntt, const double* __restrict__ key_inf, const DevTables* __restrict__ Tp,
             const uint32_t* __restrict__ tw_all, uint32_t* __restrict__ scratch, uint8_t* __restrict__ flags,
@@ -960,7 +973,7 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
             const bool vec = HAS_VEC && im.kind == ITEM_VEC;
             // the resident key entry of row A's product is requested before the transform, which hides its latency
             // (N <= 1024; at N = 2048 the registers are not there and the entry is loaded after the transform)
-            constexpr bool EARLY = LOGN <= 10;
+            constexpr bool EARLY = LOGN <= 10 && !HAS_VEC;   // (and not next to vector x vector items: their second transform needs the registers)
             uint32_t kreg[E];
             const uint4* __restrict__ kpA = reinterpret_cast<const uint4*>(key_ntt + ((size_t)im.keyA * kMaxPrimes + pi) * N);
             if (EARLY && !vec && im.keyA != kNoKey) {
@@ -1000,10 +1013,10 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
               if (pair && im.keyB != kNoKey) boundB += key_inf[im.keyB] * l1b;
             }
             const bool feedsA = vec || im.keyA != kNoKey;
-            const uint32_t* mulA = vec ? xb : kreg;
             if (!last) {
               RZK_T0();
-              if (feedsA) mac_park<LOGN, false>(x, mulA, im.signA < 0, P4, ln, it == 0, pc);
+              if (vec) mac_park<LOGN, false>(x, xb, im.signA < 0, P4, ln, it == 0, pc);
+              else if (feedsA) mac_park<LOGN, false>(x, kreg, im.signA < 0, P4, ln, it == 0, pc);
               RZK_T1(t_mac);
               continue;
             }
@@ -1013,8 +1026,10 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
             if (first) np = primes_for(boundA > boundB ? boundA : boundB, T);
 #pragma unroll
             for (int c = 0; c < E; ++c) acc[c] = x[c];
-            if (feedsA) {
-              mac_park<LOGN, true>(acc, mulA, im.signA < 0, P4, ln, it == 0, pc);
+            if (vec) {
+              mac_park<LOGN, true>(acc, xb, im.signA < 0, P4, ln, it == 0, pc);
+            } else if (feedsA) {
+              mac_park<LOGN, true>(acc, kreg, im.signA < 0, P4, ln, it == 0, pc);
             } else {   // (an item that only feeds row B)
 #pragma unroll
               for (int g = 0; g < E / 4; ++g) {
@@ -1024,16 +1039,13 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
             }
             if (pair) {   // ... and row B's only product, from the same transform, takes its place in P
               const uint4* __restrict__ kb = reinterpret_cast<const uint4*>(key_ntt + ((size_t)im.keyB * kMaxPrimes + pi) * N);
+              uint32_t kbr[E];
 #pragma unroll
               for (int g = 0; g < E / 4; ++g) {
                 const uint4 kv = kb[g * 64 + ln];
-                const uint32_t ks[4] = {kv.x, kv.y, kv.z, kv.w};
-                uint32_t bs[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                  bs[i] = im.signB < 0 ? mac_sub(0u, x[4 * g + i], ks[i], pc) : mac_add(0u, x[4 * g + i], ks[i], pc);
-                P4[g * 64 + ln] = make_uint4(bs[0], bs[1], bs[2], bs[3]);
+                kbr[4 * g] = kv.x, kbr[4 * g + 1] = kv.y, kbr[4 * g + 2] = kv.z, kbr[4 * g + 3] = kv.w;
               }
+              mac_park<LOGN, false>(x, kbr, im.signB < 0, P4, ln, true, pc);
             }
             RZK_T1(t_mac);
           }

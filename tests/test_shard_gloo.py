@@ -43,6 +43,12 @@ def _worker(rank, world, port, total, q):
         shard.barrier(dist)
         elapsed = 0.25 * (rank + 1)
         mx, acc = shard.reduce_result(dist, elapsed, int(flags.sum()), torch.device("cpu"))
+        mx2, acc2, per_rank = shard.reduce_result(dist, elapsed, int(flags.sum()), torch.device("cpu"), gather=True)
+        assert (mx2, acc2) == (mx, acc) and per_rank[rank] == int(flags.sum()) and sum(per_rank) == acc
+        # key broadcast: rank 0 owns the [a1;a2] slab, the others start from zeros (bench.py --broadcast-key)
+        key = torch.arange(2 * 3 * 16, dtype=torch.int64).reshape(2, 3, 16) - 40 if rank == 0 else torch.zeros(2, 3, 16, dtype=torch.int64)
+        key = shard.broadcast_key(dist, key, torch.device("cpu"))
+        assert torch.equal(key, torch.arange(2 * 3 * 16, dtype=torch.int64).reshape(2, 3, 16) - 40)
         full = shard.gather_flags(dist, flags, total, dst=0)
         q.put((rank, lo, hi, mx, acc, None if full is None else full.numpy().tolist()))
         shard.barrier(dist)

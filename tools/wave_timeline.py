@@ -28,8 +28,15 @@ x = ctx.sample_uniform(1, 0, half, (B, 1))
 r = ctx.sample_uniform(1, 1, 1, (B, 3))
 y = ctx.sample_gauss(1, 2, float(ctx.sigma), (B, 3))
 d = ctx.sample_challenge(1, 3, (B,))
+what = os.environ.get("RZK_TIMELINE_OP", "open_commit")
+a_, b_ = ctx.sample_uniform(1, 7, half, (B,)), ctx.sample_uniform(1, 8, half, (B,))
 for _ in range(300):
-    c, t, ok = ctx.open_commit(x, r, y)
+    if what == "polymul":
+        o = ctx.polymul(a_, b_)
+    elif what == "matvec1":
+        o = ctx.matvec(0, y)
+    else:
+        c, t, ok = ctx.open_commit(x, r, y)
 torch.cuda.synchronize()
 tot = C.c_size_t(0)
 ctx._L.rzk_debug_read_scratch(ctx._h, None, 0, C.byref(tot))

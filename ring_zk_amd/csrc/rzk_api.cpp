@@ -96,6 +96,7 @@ struct rzk_ctx {
   uint32_t* d_block_scratch = nullptr; // per-workgroup Garner state of the row-block kernel (allocated on first use)
   uint32_t block_min_logn = 11;        // row blocks from this ring degree on (below it row groups do the sharing)
   bool use_groups = true;
+  uint32_t units_per_task = 0;         // 0 = automatic (RZK_UPT overrides, tuning)
   bool use_pairs = true;               // unit_kernel: pair rows that share their last operand (RZK_PAIRS=0 turns it off, tuning)
   int group_max = 1;                   // rows per group of row_group_kernel (group_max_for; RZK_GROUP_MAX overrides, tuning)
   bool use_shift = true;               // challenge products as signed rotations (shift_row_kernel) instead of transforms
@@ -831,7 +832,8 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
   } else {
     // one wavefront per batch entry (all units back to back: equal-cost tasks, no tail) once the batch alone fills
     // the chip's wave slots; one unit per task below that
-    const uint32_t upt = batch >= (uint64_t)c->num_cus * 16 ? dp.nunits : 1;
+    uint32_t upt = batch >= (uint64_t)c->num_cus * 16 ? dp.nunits : 1;
+    if (c->units_per_task) upt = c->units_per_task;   // RZK_UPT (tuning)
     lrc = launch_units((int)c->logn, cfg_of(c), dp.d, dp.d_wp, dp.nunits, upt, 2 * dp.work, dp.has_vec, dp.has_shift, ops, c->d_key_ntt,
                        c->d_key_inf, c->dT, c->d_tw, c->d_row_scratch, flags, batch);
   }
@@ -1006,6 +1008,7 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
   }
   if (const char* e = std::getenv("RZK_SHIFT")) c->use_shift = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_PAIRS")) c->use_pairs = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RZK_UPT")) c->units_per_task = (uint32_t)std::atoi(e);
   if (const char* e = std::getenv("RZK_BLOCK_MIN_LOGN")) c->block_min_logn = (uint32_t)std::atoi(e);   // 12 = never
 
   // twiddle tables: 3 primes x {fwd, inv} x kTableLen

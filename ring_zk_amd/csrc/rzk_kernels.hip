@@ -648,38 +648,34 @@ __device__ __forceinline__ void set_rank_priority(FairTable* ft, uint32_t simd, 
 
 // x (transform, phase-3 register order) times `mul` (a resident key entry or a second transform, in registers), into
 // row A's accumulator.  init: nothing accumulated yet; to_regs: the unit's last item -> the sum replaces x, else -> P
+template <int LOGN, bool to_regs, bool MINUS>
+__device__ __forceinline__ void mac_park_signed(uint32_t* x, const uint32_t* mul, uint4* P4, int lane, bool init,
+                                                const PrimeConsts& pc) {
+  constexpr int E = Geo<LOGN>::E;
+#pragma unroll
+  for (int g = 0; g < E / 4; ++g) {
+    uint4 a = make_uint4(0, 0, 0, 0);
+    if (!init) a = P4[g * 64 + lane];
+    uint32_t as[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      as[i] = MINUS ? mac_sub(as[i], x[4 * g + i], mul[4 * g + i], pc) : mac_add(as[i], x[4 * g + i], mul[4 * g + i], pc);
+    if (to_regs) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[4 * g + i] = as[i];
+    } else {
+      P4[g * 64 + lane] = make_uint4(as[0], as[1], as[2], as[3]);
+    }
+  }
+}
+// (the sign is tested once, outside the element loops: a per-element select of mac_add / mac_sub made the compiler
+// branch per coefficient; `mul` must be a register array of the caller, never a pointer chosen at run time, or both
+// candidates end up in scratch memory)
 template <int LOGN, bool to_regs>
 __device__ __forceinline__ void mac_park(uint32_t* x, const uint32_t* mul, bool minus, uint4* P4, int lane, bool init,
                                          const PrimeConsts& pc) {
-  // (the sign is tested once, outside the element loops: a per-element select of mac_add / mac_sub made the
-  // compiler branch per coefficient; `mul` must be a register array of the caller, never a pointer chosen at run time,
-  // or both candidates end up in scratch memory)
-  constexpr int E = Geo<LOGN>::E;
-  uint32_t as[E];
-  if (init) {
-#pragma unroll
-    for (int c = 0; c < E; ++c) as[c] = 0;
-  } else {
-#pragma unroll
-    for (int g = 0; g < E / 4; ++g) {
-      const uint4 a = P4[g * 64 + lane];
-      as[4 * g] = a.x, as[4 * g + 1] = a.y, as[4 * g + 2] = a.z, as[4 * g + 3] = a.w;
-    }
-  }
-  if (minus) {
-#pragma unroll
-    for (int c = 0; c < E; ++c) as[c] = mac_sub(as[c], x[c], mul[c], pc);
-  } else {
-#pragma unroll
-    for (int c = 0; c < E; ++c) as[c] = mac_add(as[c], x[c], mul[c], pc);
-  }
-  if (to_regs) {
-#pragma unroll
-    for (int c = 0; c < E; ++c) x[c] = as[c];
-  } else {
-#pragma unroll
-    for (int g = 0; g < E / 4; ++g) P4[g * 64 + lane] = make_uint4(as[4 * g], as[4 * g + 1], as[4 * g + 2], as[4 * g + 3]);
-  }
+  if (minus) mac_park_signed<LOGN, to_regs, true>(x, mul, P4, lane, init, pc);
+  else mac_park_signed<LOGN, to_regs, false>(x, mul, P4, lane, init, pc);
 }
 
 // Inverse transform of a finished accumulator and Garner step `pi` of `np` against the row's global state lines.
@@ -854,7 +850,7 @@ struct UnitCfg {
 };
 
 template <int LOGN, bool HAS_VEC, bool HAS_SHIFT>
-__global__ void __launch_bounds__(64 * UnitCfg<LOGN>::WPB, (LOGN <= 10 ? 4 : 1))   // N <= 1024: LDS allows 4 waves per SIMD
+__global__ void __launch_bounds__(64 * UnitCfg<LOGN>::WPB, (LOGN <= 10 && HAS_VEC ? 4 : 1))   // vector x vector variants: hold the 4 waves per SIMD the LDS allows
 unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp, const Operands ops,
             const uint32_t* __restrict__ key_ntt, const double* __restrict__ key_inf, const DevTables* __restrict__ Tp,
             const uint32_t* __restrict__ tw_all, uint32_t* __restrict__ scratch, uint8_t* __restrict__ flags,
@@ -896,6 +892,10 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
   const uint32_t nunits = wp->nunits;
 
   // progress of this wave through its share of the launch, in transforms (work_per_task: the host's estimate)
+#ifndef RZK_UNIT_ROT
+#define RZK_UNIT_ROT 0   // (rotating the unit order per workgroup measured no gain)
+#endif
+  const uint32_t rot_sel = RZK_UNIT_ROT == 1 ? (blockIdx.x >> 8) : (RZK_UNIT_ROT == 2 ? blockIdx.x : 0u);
   const uint32_t first_task = blockIdx.x * WPB + wave;
   const uint32_t my_tasks = first_task < ntasks ? (ntasks - first_task + gridDim.x * WPB - 1) / (gridDim.x * WPB) : 0;
   const uint32_t work_total = my_tasks * work_per_task;
@@ -912,8 +912,13 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
     const uint32_t u0 = (task - b * tasks_per_entry) * units_per_task;
     const uint32_t u1 = u0 + units_per_task < nunits ? u0 + units_per_task : nunits;
     const uint32_t bo = ops.group > 1 ? b / ops.group : b;
+    const uint32_t unit_rot = (u1 - u0) > 1 ? rot_sel % (u1 - u0) : 0u;
 #pragma unroll 1
-    for (uint32_t ui = u0; ui < u1; ++ui) {
+    for (uint32_t uk = u0; uk < u1; ++uk) {
+      // waves start their task at different units (by workgroup), so that SIMD mates are not all in the same kind of
+      // step (load / transform / store) at the same time; the units of an entry are independent of each other
+      uint32_t ui = uk + unit_rot;
+      if (ui >= u1) ui -= u1 - u0;
       const Unit un = table_load(&wp->units[ui]);
       const Row rowA = table_load(&prog->rows[un.rowA]);
       const bool pair = un.rowB != kNoRow;

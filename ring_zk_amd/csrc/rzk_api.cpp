@@ -59,6 +59,7 @@ struct DevProg {
   WaveProgram* d_wp = nullptr;   // units / items of unit_kernel (the default path)
   uint32_t nunits = 0;
   uint32_t work = 0;             // steps (item + inverse trips) of one batch entry per prime pass
+  bool all_short = false;        // every unit is short (<= 2 key items, no vector x vector item): short_kernel
   bool has_vec = false;
   // shared-operand path (fwd_slots_kernel + row_slots_kernel), chosen when rows share enough operands
   SlotTable* d_slots = nullptr;
@@ -97,6 +98,8 @@ struct rzk_ctx {
   uint32_t block_min_logn = 11;        // row blocks from this ring degree on (below it row groups do the sharing)
   bool use_groups = true;
   uint32_t units_per_task = 0;         // 0 = automatic (RZK_UPT overrides, tuning)
+  bool use_short = true;               // short_kernel for programs made of short units (RZK_SHORT=0 turns it off, tuning)
+  bool use_split = true;               // short_kernel: split evaluation for small-norm operands (RZK_SPLIT=0, tuning)
   bool use_pairs = true;               // unit_kernel: pair rows that share their last operand (RZK_PAIRS=0 turns it off, tuning)
   int group_max = 1;                   // rows per group of row_group_kernel (group_max_for; RZK_GROUP_MAX overrides, tuning)
   bool use_shift = true;               // challenge products as signed rotations (shift_row_kernel) instead of transforms
@@ -685,14 +688,17 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
           }
         }
       }
+      if (ra.nterms <= 2 && key_only(ra)) un.nitems |= kUnitShort;
       r += step;
     }
+    dp.all_short = wp.nunits > 0;
+    for (uint32_t u = 0; u < wp.nunits; ++u) dp.all_short = dp.all_short && (wp.units[u].nitems & kUnitShort);
     HIPCHK(c, hipMalloc((void**)&dp.d_wp, sizeof(WaveProgram)));
     HIPCHK(c, hipMemcpyAsync(dp.d_wp, &wp, sizeof(WaveProgram), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     dp.nunits = wp.nunits;
     for (uint32_t u = 0; u < wp.nunits; ++u)
-      dp.work += (wp.units[u].nitems ? wp.units[u].nitems : 1u) + (wp.units[u].rowB != kNoRow ? 2u : 1u);
+      dp.work += ((wp.units[u].nitems & kUnitItemsMask) ? (wp.units[u].nitems & kUnitItemsMask) : 1u) + (wp.units[u].rowB != kNoRow ? 2u : 1u);
   }
   for (uint32_t t = 0; t < pb.p.nterms; ++t) dp.has_vec = dp.has_vec || (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_VEC;
   // distinct operands of the product terms ("slots"); when rows share them often enough, transform each
@@ -834,8 +840,12 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
     // the chip's wave slots; one unit per task below that
     uint32_t upt = batch >= (uint64_t)c->num_cus * 16 ? dp.nunits : 1;
     if (c->units_per_task) upt = c->units_per_task;   // RZK_UPT (tuning)
-    lrc = launch_units((int)c->logn, cfg_of(c), dp.d, dp.d_wp, dp.nunits, upt, 2 * dp.work, dp.has_vec, dp.has_shift, ops, c->d_key_ntt,
-                       c->d_key_inf, c->dT, c->d_tw, c->d_row_scratch, flags, batch);
+    if (dp.all_short && c->use_short)
+      lrc = launch_short((int)c->logn, cfg_of(c), dp.d, dp.d_wp, dp.nunits, upt, 2 * dp.work + dp.nunits, dp.has_shift, c->use_split,
+                         ops, c->d_key_ntt, c->d_key_inf, c->dT, c->d_tw, c->d_row_scratch, flags, batch);
+    else
+      lrc = launch_units((int)c->logn, cfg_of(c), dp.d, dp.d_wp, dp.nunits, upt, 2 * dp.work, dp.has_vec, dp.has_shift, ops,
+                         c->d_key_ntt, c->d_key_inf, c->dT, c->d_tw, c->d_row_scratch, flags, batch);
   }
   if (lrc == -2) return fail(c, RZK_E_UNSUPPORTED, "batch * rows must stay below 2^32");
   if (lrc != 0) {
@@ -1009,6 +1019,8 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
   if (const char* e = std::getenv("RZK_SHIFT")) c->use_shift = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_PAIRS")) c->use_pairs = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_UPT")) c->units_per_task = (uint32_t)std::atoi(e);
+  if (const char* e = std::getenv("RZK_SHORT")) c->use_short = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RZK_SPLIT")) c->use_split = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_BLOCK_MIN_LOGN")) c->block_min_logn = (uint32_t)std::atoi(e);   // 12 = never
 
   // twiddle tables: 3 primes x {fwd, inv} x kTableLen
@@ -1148,7 +1160,7 @@ static int key_load_impl(rzk_ctx* c, const int64_t* a_host) {
     const size_t gbytes = general.size() * sizeof(int64_t);
     int rc = arena_reserve(c, c->stage, gbytes);
     if (rc != RZK_OK) return rc;
-    HIPCHK(c, hipMalloc((void**)&c->d_key_ntt, (size_t)c->n_general * kMaxPrimes * N * sizeof(uint32_t)));
+    HIPCHK(c, hipMalloc((void**)&c->d_key_ntt, (size_t)c->n_general * kKeyImages * N * sizeof(uint32_t)));
     HIPCHK(c, hipMalloc((void**)&c->d_key_inf, (size_t)c->n_general * sizeof(double)));
     HIPCHK(c, hipMemcpyAsync(c->stage.p, general.data(), gbytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_key_inf, kinf.data(), kinf.size() * sizeof(double), hipMemcpyHostToDevice,

@@ -120,9 +120,11 @@ struct alignas(8) Item {
   int8_t signA, signB;
   uint16_t pad;
 };
+constexpr uint16_t kUnitShort = 0x8000;       // in Unit::nitems: key products over at most two operands (short_kernel)
+constexpr uint16_t kUnitItemsMask = 0x7fff;
 struct alignas(8) Unit {
-  uint16_t rowA, rowB;   // indices into Program::rows; rowB = kNoRow for a single row
-  uint16_t item0, nitems;
+  uint16_t rowA, rowB;      // indices into Program::rows; rowB = kNoRow for a single row
+  uint16_t item0, nitems;   // nitems & kUnitItemsMask items from item0 on; kUnitShort flag
 };
 struct WaveProgram {
   uint32_t nunits, nitems;
@@ -182,6 +184,12 @@ struct LaunchCfg {
 
 // units_per_task: how many consecutive units of one batch entry a wavefront evaluates back to back (all of them =
 // one wavefront per proof: equal-cost tasks, no tail)
+// Programs whose units are all short (<= 2 key items per row, pairs allowed): short_kernel — every operand loaded once,
+// one-prime / split / two-prime-interleaved evaluation chosen per unit from the operands' norms (rzk_kernels.hip)
+int launch_short(int logn, const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, uint32_t nunits,
+                 uint32_t units_per_task, uint32_t work_per_entry, bool has_shift, bool allow_split, const Operands& ops,
+                 const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* d_T, const uint32_t* d_tw,
+                 uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch);
 // work_per_entry: transforms one batch entry costs at two primes (the progress priorities only need an estimate)
 int launch_units(int logn, const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, uint32_t nunits,
                  uint32_t units_per_task, uint32_t work_per_entry, bool has_vec, bool has_shift, const Operands& ops,

@@ -416,7 +416,7 @@ __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const 
     }
   } else {
     if (first) bound += key_inf[tm.a_off] * l1b;
-    const uint4* __restrict__ kp = reinterpret_cast<const uint4*>(key_ntt + ((size_t)tm.a_off * kMaxPrimes + pi) * N);
+    const uint4* __restrict__ kp = reinterpret_cast<const uint4*>(key_ntt + ((size_t)tm.a_off * kKeyImages + pi) * N);
     if (tm.sign >= 0) {
 #pragma unroll
       for (int g = 0; g < E / 4; ++g) {
@@ -585,6 +585,8 @@ __device__ __forceinline__ int primes_for(double bound, const DevTables& T) {
 //     2N-word image in the (then idle) slab + P.
 // LDS per wavefront: transposition slab (N + N/32 words) + P (N words) = 8.1 KiB at N = 1024.
 // =============================================================================================
+// lines (of N words) of per-wave global scratch the unit / short kernels address
+constexpr int kScratchLines = 6;
 #ifndef RZK_UNIT_MIN_WAVES
 #define RZK_UNIT_MIN_WAVES 1
 #endif
@@ -880,7 +882,7 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
     my_slot = __builtin_amdgcn_readfirstlane(sl) & 3u;
   }
   // per-wave global scratch: Garner words [row A | B][word A | B][N], then the sum of row A's rotation terms
-  uint32_t* st = scratch + ((size_t)blockIdx.x * WPB + wave) * (size_t)(5 * N + 16);
+  uint32_t* st = scratch + ((size_t)blockIdx.x * WPB + wave) * (size_t)(kScratchLines * N + 16);
   uint32_t* st_sh = st + 4 * N;
 #if RZK_STAMPS   // diagnostic build only (tools/wave_timeline.py): when each wavefront ran and where
   const uint64_t stamp0 = __builtin_amdgcn_s_memrealtime();
@@ -922,7 +924,8 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
       const Unit un = table_load(&wp->units[ui]);
       const Row rowA = table_load(&prog->rows[un.rowA]);
       const bool pair = un.rowB != kNoRow;
-      const bool null_unit = un.nitems == 0;   // no products: additions / rotation terms only
+      const uint32_t un_items = un.nitems & kUnitItemsMask;   // (the kUnitShort flag rides in the same field)
+      const bool null_unit = un_items == 0;   // no products: additions / rotation terms only
       const bool has_shift = HAS_SHIFT && rowA.nshift > 0;
       if (has_shift) {
         // challenge products first (rotations, image in slab + P); their sum mod q is built in the wave's scratch line
@@ -944,7 +947,7 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
         wave_sync();   // the image is dead: slab and P may be overwritten
       }
       int np = null_unit ? 1 : kMaxPrimes;
-      const uint32_t nit = null_unit ? 1u : (uint32_t)un.nitems;
+      const uint32_t nit = null_unit ? 1u : un_items;
       double boundA = 0.0, boundB = 0.0;
 #pragma unroll 1
       for (int pi = 0; pi < np; ++pi) {
@@ -980,7 +983,7 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
             // (N <= 1024; at N = 2048 the registers are not there and the entry is loaded after the transform)
             constexpr bool EARLY = LOGN <= 10 && !HAS_VEC;   // (and not next to vector x vector items: their second transform needs the registers)
             uint32_t kreg[E];
-            const uint4* __restrict__ kpA = reinterpret_cast<const uint4*>(key_ntt + ((size_t)im.keyA * kMaxPrimes + pi) * N);
+            const uint4* __restrict__ kpA = reinterpret_cast<const uint4*>(key_ntt + ((size_t)im.keyA * kKeyImages + pi) * N);
             if (EARLY && !vec && im.keyA != kNoKey) {
 #pragma unroll
               for (int g = 0; g < E / 4; ++g) {
@@ -1043,7 +1046,7 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
               }
             }
             if (pair) {   // ... and row B's only product, from the same transform, takes its place in P
-              const uint4* __restrict__ kb = reinterpret_cast<const uint4*>(key_ntt + ((size_t)im.keyB * kMaxPrimes + pi) * N);
+              const uint4* __restrict__ kb = reinterpret_cast<const uint4*>(key_ntt + ((size_t)im.keyB * kKeyImages + pi) * N);
               uint32_t kbr[E];
 #pragma unroll
               for (int g = 0; g < E / 4; ++g) {
@@ -1092,7 +1095,7 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
     uint32_t xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    uint32_t* o = st + 5 * N;
+    uint32_t* o = st + kScratchLines * N;
     o[0] = (uint32_t)stamp0, o[1] = (uint32_t)(stamp0 >> 32), o[2] = (uint32_t)stamp1, o[3] = (uint32_t)(stamp1 >> 32);
     o[4] = hwid, o[5] = xcc, o[6] = blockIdx.x, o[7] = wave;
     const uint64_t cyc1 = __builtin_amdgcn_s_memtime();
@@ -1100,6 +1103,419 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
     o[9] = (uint32_t)t_load, o[10] = (uint32_t)t_fwd, o[11] = (uint32_t)t_mac, o[12] = (uint32_t)t_inv, o[13] = (uint32_t)t_fin;
   }
 #endif
+}
+
+// =============================================================================================
+// short_kernel: programs whose units are all SHORT — key products over at most two operands per row, optionally a
+// pair (rzk_dev.h) — which is every key-product program of the (1,3,1) parameter family: the commitment rows, t = a1.y,
+// the verifier relation a1.z - c1 (.) d - t, a2.v ...  One wavefront per unit, and every operand is loaded ONCE:
+// both operands' raw low words sit in registers while their norms decide, before any transform, how the exact
+// integer products are obtained:
+//   ONE    bound <= cap(1 prime): one pass under prime 0;
+//   SPLIT  operands of small 1-norm (2^15 * sum |v|_1 <= cap(1 prime): the ternary randomness of a commitment): one
+//          pass under prime 0 against the two 16-bit HALVES of the key entries (rzk_core.h, kKeyImages), value =
+//          lo + 2^16 hi — one forward transform per operand instead of two, no Garner step;
+//   TWO    both primes interleaved per operand (transform under p0, then under p1, from the same registers): row A's
+//          p0-sum waits in P, its p1-sum in registers, the two residues meet in registers — no Garner state in memory;
+//   THREE  TWO, whose result becomes the Garner words (scratch line), then a third pass under prime 2 (operands re-read).
+// In the single-pass modes the transforms wait in P (first operand) and in the wave's scratch line (last operand) while
+// the rows' sums are formed and transformed back one after the other, so that only the accumulator is live during a
+// transform.  Boundary traffic of an Open commit: 7 polynomials in, 3 out — the algorithmic minimum.
+// =============================================================================================
+template <int LOGN>
+__device__ __forceinline__ void load_raw(int32_t* v, const int64_t* __restrict__ src, int lane, uint32_t qhalf, double& l1,
+                                         bool want_sq, uint64_t& sumsq, bool& fault) {
+  using G = Geo<LOGN>;
+  uint32_t bad = 0;
+#pragma unroll
+  for (int e = 0; e < G::E; ++e) v[e] = canon_lo(src[G::j_p1(lane, e)], qhalf, bad);
+  uint64_t sum = 0;
+  uint32_t mx = 0;
+#pragma unroll
+  for (int e = 0; e < G::E; e += 2) {
+    const uint32_t a0 = (uint32_t)(v[e] < 0 ? -v[e] : v[e]);
+    const uint32_t a1 = (uint32_t)(v[e + 1] < 0 ? -v[e + 1] : v[e + 1]);
+    sum += (uint64_t)a0 + a1;
+    mx = a0 > mx ? a0 : mx;
+    mx = a1 > mx ? a1 : mx;
+  }
+  l1 = (double)wave_sum_u64(sum);
+  fault = fault || __any(bad != 0) || wave_max_u32(mx) > qhalf;
+  if (want_sq) {
+    uint64_t sq = 0;
+#pragma unroll
+    for (int e = 0; e < G::E; ++e) {
+      uint32_t a = (uint32_t)(v[e] < 0 ? -v[e] : v[e]);
+      a = a < (1u << 24) ? a : (1u << 24);
+      sq += (uint64_t)a * a;
+    }
+    sumsq = wave_sum_u64(sq);
+  }
+}
+
+// P (+/-)= KEY image (*) x   (row A's running sum under one prime, parked in LDS)
+template <int LOGN>
+__device__ __forceinline__ void mac_into_P(const uint32_t* x, const uint4* __restrict__ kp, bool minus, uint4* P4, int lane,
+                                           bool init, const PrimeConsts& pc) {
+  constexpr int E = Geo<LOGN>::E;
+#pragma unroll
+  for (int g = 0; g < E / 4; ++g) {
+    const uint4 kv = kp[g * 64 + lane];
+    const uint32_t ks[4] = {kv.x, kv.y, kv.z, kv.w};
+    uint4 a = make_uint4(0, 0, 0, 0);
+    if (!init) a = P4[g * 64 + lane];
+    uint32_t as[4] = {a.x, a.y, a.z, a.w};
+    if (minus) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) as[i] = mac_sub(as[i], x[4 * g + i], ks[i], pc);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) as[i] = mac_add(as[i], x[4 * g + i], ks[i], pc);
+    }
+    P4[g * 64 + lane] = make_uint4(as[0], as[1], as[2], as[3]);
+  }
+}
+
+// acc +/-= KEY image (global, 16-byte loads) (*) x, where x is a register array or, with FROM_MEM, a transform parked in
+// P (LDS) or in the wave's scratch line (key layout, 16-byte slots); four coefficients at a time, sign tested once
+template <int LOGN, bool FROM_MEM, bool MINUS, class XP>
+__device__ __forceinline__ void mac_key_signed(uint32_t* acc, const uint32_t* x, XP X4, const uint4* __restrict__ kp, int lane,
+                                               const PrimeConsts& pc) {
+  constexpr int E = Geo<LOGN>::E;
+#pragma unroll
+  for (int g = 0; g < E / 4; ++g) {
+    const uint4 kv = kp[g * 64 + lane];
+    const uint32_t ks[4] = {kv.x, kv.y, kv.z, kv.w};
+    uint32_t xs[4];
+    if (FROM_MEM) {
+      const uint4 xv = X4[g * 64 + lane];
+      xs[0] = xv.x, xs[1] = xv.y, xs[2] = xv.z, xs[3] = xv.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xs[i] = x[4 * g + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      acc[4 * g + i] = MINUS ? mac_sub(acc[4 * g + i], xs[i], ks[i], pc) : mac_add(acc[4 * g + i], xs[i], ks[i], pc);
+  }
+}
+template <int LOGN, bool FROM_MEM, class XP>
+__device__ __forceinline__ void mac_key(uint32_t* acc, const uint32_t* x, XP X4, const uint4* __restrict__ kp, bool minus, int lane,
+                                        const PrimeConsts& pc) {
+  if (minus) mac_key_signed<LOGN, FROM_MEM, true>(acc, x, X4, kp, lane, pc);
+  else mac_key_signed<LOGN, FROM_MEM, false>(acc, x, X4, kp, lane, pc);
+}
+
+enum : int { SHORT_ONE = 0, SHORT_SPLIT = 1, SHORT_TWO = 2, SHORT_THREE = 3 };
+
+template <int LOGN, bool HAS_SHIFT>
+__global__ void __launch_bounds__(256)
+short_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp, const Operands ops,
+             const uint32_t* __restrict__ key_ntt, const double* __restrict__ key_inf, const DevTables* __restrict__ Tp,
+             const uint32_t* __restrict__ tw_all, uint32_t* __restrict__ scratch, uint8_t* __restrict__ flags,
+             const uint32_t ntasks, const uint32_t units_per_task, const uint32_t tasks_per_entry,
+             const uint32_t work_per_task, const uint32_t allow_split) {
+  using G = Geo<LOGN>;
+  constexpr int E = G::E;
+  constexpr int N = G::N;
+  constexpr bool OPQ = true;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t* lds = smem + wave * (G::LDS_WORDS + N);             // transposition slab, then P
+  uint4* P4 = reinterpret_cast<uint4*>(lds + G::LDS_WORDS);
+  // per-wave global scratch: [0,4N) Garner words [row A | B][word A | B] (rows B's lines double as its parked sums in
+  // mode TWO), [4N,5N) sum of row A's rotation terms, [5N,6N) the last operand's transform of the single-pass modes
+  uint32_t* st = scratch + ((size_t)blockIdx.x * 4 + wave) * (size_t)(kScratchLines * N + 16);
+  uint32_t* st_sh = st + 4 * N;
+  uint4* XL = reinterpret_cast<uint4*>(st + 5 * N);
+  const DevTables& T = *Tp;
+  const uint32_t qhalf = T.crt.qhalf;
+  const uint32_t nunits = wp->nunits;
+  const uint32_t first_task = blockIdx.x * 4 + wave;
+  const uint32_t my_tasks = first_task < ntasks ? (ntasks - first_task + gridDim.x * 4 - 1) / (gridDim.x * 4) : 0;
+  const uint32_t work_total = my_tasks * work_per_task;
+  uint32_t work_done = 0;
+#define RZK_STEP_PRIORITY()                         \
+  do {                                              \
+    set_progress_priority(work_done, work_total);   \
+    ++work_done;                                    \
+  } while (0)
+
+  for (uint32_t task = first_task; task < ntasks; task += gridDim.x * 4) {
+    const uint32_t b = task / tasks_per_entry;
+    const uint32_t u0 = (task - b * tasks_per_entry) * units_per_task;
+    const uint32_t u1 = u0 + units_per_task < nunits ? u0 + units_per_task : nunits;
+    const uint32_t bo = ops.group > 1 ? b / ops.group : b;
+#pragma unroll 1
+    for (uint32_t ui = u0; ui < u1; ++ui) {
+      const Unit un = table_load(&wp->units[ui]);
+      const Row rowA = table_load(&prog->rows[un.rowA]);
+      const bool pair = un.rowB != kNoRow;
+      const uint32_t nit = un.nitems & kUnitItemsMask;   // 0 (additions / rotations only), 1 or 2
+      const bool has_shift = HAS_SHIFT && rowA.nshift > 0;
+      bool fault = false;
+      if (has_shift) {
+        // challenge products first (rotations, image in slab + P); their sum mod q waits in the wave's scratch line
+#pragma unroll 1
+        for (uint32_t t = 0; t < rowA.nshift; ++t) {
+          const Term tm = table_load(&prog->terms[rowA.term0 + rowA.nterms + t]);
+          const int64_t* __restrict__ pa = operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N);
+          int32_t a[E];
+          uint32_t abad = 0, amx = 0;
+#pragma unroll
+          for (int e = 0; e < E; ++e) a[e] = canon_lo_mx(pa[G::j_p1(lane, e)], qhalf, abad, amx);
+          fault = fault || canon_fail(abad, amx, qhalf);
+          shift_product<LOGN, false, true>(st_sh, t == 0, tm.sign < 0, a, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane,
+                                           reinterpret_cast<int32_t*>(lds), T, fault);
+        }
+        wave_sync();   // the image is dead: slab and P may be overwritten
+      }
+      if (nit == 0) {
+        if (fault) input_fault(ops, flags, bo, lane);
+        uint32_t u[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) u[e] = 0;
+        finish_row<LOGN>(u, prog, rowA, ops, b, bo, lane, T, flags, has_shift ? st_sh : nullptr);
+        continue;
+      }
+      const Item i1 = table_load(&wp->items[un.item0 + nit - 1]);   // the last operand (feeds row A and a pair's row B)
+      const Item i0 = table_load(&wp->items[un.item0]);             // nit == 2: the first operand (row A only)
+      const int64_t* __restrict__ src0 = operand_ptr(ops, i0.b_op, i0.b_off, b, bo, N);
+      const int64_t* __restrict__ src1 = operand_ptr(ops, i1.b_op, i1.b_off, b, bo, N);
+      // ---- both operands: raw low words into registers (one pass over HBM), canonical test, norms, norm marks
+      int32_t v0[E], v1[E];
+      double l10 = 0.0, l11 = 0.0;
+      {
+        RZK_STEP_PRIORITY();
+        uint64_t sq = 0;
+        if (nit == 2) {
+          const bool chk = (i0.flags & (TERM_CHECK | TERM_CHECK2)) != 0;
+          load_raw<LOGN>(v0, src0, lane, qhalf, l10, chk, sq, fault);
+          if (chk && sq >= ops.norm_limit && lane == 0) fail_check(flags + bo, ops.pad != 0, (i0.flags & TERM_CHECK2) != 0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < E; ++e) v0[e] = 0;
+        }
+        const bool chk1 = (i1.flags & (TERM_CHECK | TERM_CHECK2)) != 0;
+        load_raw<LOGN>(v1, src1, lane, qhalf, l11, chk1, sq, fault);
+        if (chk1 && sq >= ops.norm_limit && lane == 0) fail_check(flags + bo, ops.pad != 0, (i1.flags & TERM_CHECK2) != 0);
+      }
+      if (fault) input_fault(ops, flags, bo, lane);
+      const double boundA = (nit == 2 ? key_inf[i0.keyA] * l10 : 0.0) + (i1.keyA != kNoKey ? key_inf[i1.keyA] * l11 : 0.0);
+      const double boundB = pair ? key_inf[i1.keyB] * l11 : 0.0;
+      const int np = primes_for(boundA > boundB ? boundA : boundB, T);
+      int mode = np == 1 ? SHORT_ONE : (np == 2 ? SHORT_TWO : SHORT_THREE);
+      if (np == 2 && allow_split && 32768.0 * (l10 + l11) <= T.cap[1]) mode = SHORT_SPLIT;
+      mode = __builtin_amdgcn_readfirstlane(mode);
+
+      if (mode >= SHORT_TWO) {
+        // ---- both primes interleaved per operand; row A: p0-sum in P, p1-sum in registers; a pair's row B: scratch lines
+        uint32_t acc1[E];
+#pragma unroll
+        for (int c = 0; c < E; ++c) acc1[c] = 0;
+#pragma unroll 1
+        for (uint32_t op = 2 - nit; op < 2; ++op) {
+          const Item it = op ? i1 : i0;
+#pragma unroll 1
+          for (int p = 0; p < 2; ++p) {
+            RZK_STEP_PRIORITY();
+            const PrimeConsts pc = T.pc[p];
+            int ln = lane;
+            RZK_OPAQUE(ln);
+            uint32_t x[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) x[e] = lift(op ? v1[e] : v0[e], pc);
+            wave_fwd<LOGN>(x, ln, lds, tw_all + (size_t)(2 * p) * kTableLen, pc);
+            if (pair && op == 1) {   // row B's only product, parked in its scratch line for prime p
+              uint32_t accb[E];
+#pragma unroll
+              for (int c = 0; c < E; ++c) accb[c] = 0;
+              mac_key<LOGN, false>(accb, x, P4, reinterpret_cast<const uint4*>(key_ntt + ((size_t)it.keyB * kKeyImages + p) * N),
+                                   it.signB < 0, ln, pc);
+              uint4* __restrict__ BL = reinterpret_cast<uint4*>(st + (size_t)(2 + p) * N);
+#pragma unroll
+              for (int g = 0; g < E / 4; ++g) BL[g * 64 + ln] = make_uint4(accb[4 * g], accb[4 * g + 1], accb[4 * g + 2], accb[4 * g + 3]);
+            }
+            if (it.keyA != kNoKey) {
+              const uint4* __restrict__ ka = reinterpret_cast<const uint4*>(key_ntt + ((size_t)it.keyA * kKeyImages + p) * N);
+              if (p == 0) mac_into_P<LOGN>(x, ka, it.signA < 0, P4, ln, op + nit == 2, pc);   // first contribution initialises
+              else mac_key<LOGN, false>(acc1, x, P4, ka, it.signA < 0, ln, pc);
+            } else if (p == 0 && op + nit == 2) {   // (row A without a product on its first operand: P starts at zero)
+#pragma unroll
+              for (int g = 0; g < E / 4; ++g) P4[g * 64 + ln] = make_uint4(0, 0, 0, 0);
+            }
+          }
+        }
+        // ---- residues of the two primes meet in registers
+#pragma unroll 1
+        for (uint32_t r = 0; r < (pair ? 2u : 1u); ++r) {
+          int li = lane;
+          RZK_OPAQUE(li);
+          if (r == 1) {
+            const uint4* __restrict__ BL = reinterpret_cast<const uint4*>(st + (size_t)3 * N);
+#pragma unroll
+            for (int g = 0; g < E / 4; ++g) {
+              const uint4 v = BL[g * 64 + li];
+              acc1[4 * g] = v.x, acc1[4 * g + 1] = v.y, acc1[4 * g + 2] = v.z, acc1[4 * g + 3] = v.w;
+            }
+          }
+          RZK_STEP_PRIORITY();
+          wave_inv<LOGN>(acc1, li, lds, tw_all + (size_t)(2 * 1 + 1) * kTableLen, T.pc[1]);
+          uint32_t acc0[E];
+          if (r == 0) {
+#pragma unroll
+            for (int g = 0; g < E / 4; ++g) {
+              const uint4 v = P4[g * 64 + li];
+              acc0[4 * g] = v.x, acc0[4 * g + 1] = v.y, acc0[4 * g + 2] = v.z, acc0[4 * g + 3] = v.w;
+            }
+          } else {
+            const uint4* __restrict__ BL = reinterpret_cast<const uint4*>(st + (size_t)2 * N);
+#pragma unroll
+            for (int g = 0; g < E / 4; ++g) {
+              const uint4 v = BL[g * 64 + li];
+              acc0[4 * g] = v.x, acc0[4 * g + 1] = v.y, acc0[4 * g + 2] = v.z, acc0[4 * g + 3] = v.w;
+            }
+          }
+          RZK_STEP_PRIORITY();
+          wave_inv<LOGN>(acc0, li, lds, tw_all + (size_t)(2 * 0 + 1) * kTableLen, T.pc[0]);
+          const int npc = mode == SHORT_TWO ? 2 : 3;
+          if (mode == SHORT_TWO) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+              const uint32_t d0 = crt_fold0(acc0[e], npc, T.pc, T.crt);
+              const uint32_t d1 = crt_digit1(acc1[e], d0, npc, T.pc, T.crt);
+              acc0[e] = crt_finish_zq(crt_value01_modq(d0, d1, T.crt), 2, T.crt);
+            }
+            finish_row<LOGN>(acc0, prog, table_load(&prog->rows[r ? un.rowB : un.rowA]), ops, b, bo, lane, T, flags,
+                             (has_shift && r == 0) ? st_sh : nullptr);
+          } else {   // the Garner words of a three-prime result go to the row's state lines
+            uint4* __restrict__ A4 = reinterpret_cast<uint4*>(st + (size_t)(2 * r) * N);
+            uint4* __restrict__ B4 = reinterpret_cast<uint4*>(st + (size_t)(2 * r + 1) * N);
+#pragma unroll
+            for (int g = 0; g < E / 4; ++g) {
+              uint32_t va[4], vb[4];
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const uint32_t d0 = crt_fold0(acc0[4 * g + i], npc, T.pc, T.crt);
+                const uint32_t d1 = crt_digit1(acc1[4 * g + i], d0, npc, T.pc, T.crt);
+                va[i] = crt_value01_modq(d0, d1, T.crt);
+                vb[i] = crt_value01_modp2(d0, d1, T.pc, T.crt);
+              }
+              A4[g * 64 + li] = make_uint4(va[0], va[1], va[2], va[3]);
+              B4[g * 64 + li] = make_uint4(vb[0], vb[1], vb[2], vb[3]);
+            }
+          }
+        }
+        if (mode == SHORT_TWO) continue;
+      }
+
+      // ---- single pass under one prime (modes ONE, SPLIT; third prime of THREE): the transforms wait in P and in the
+      // scratch line while the rows' sums are formed and transformed back one after the other
+      const int pp = mode == SHORT_THREE ? 2 : 0;
+      const PrimeConsts pc = T.pc[pp];
+      const uint32_t* __restrict__ twf = tw_all + (size_t)(2 * pp) * kTableLen;
+#pragma unroll 1
+      for (uint32_t op = 2 - nit; op < 2; ++op) {
+        RZK_STEP_PRIORITY();
+        int ln = lane;
+        RZK_OPAQUE(ln);
+        uint32_t x[E];
+        if (mode == SHORT_THREE) {   // the raw words are gone: re-read the low words
+          double d0 = 0, d1 = 0;
+          uint64_t sq = 0;
+          bool f2 = false;
+          load_lift<LOGN>(x, op ? src1 : src0, ln, pc, false, d0, d1, false, sq, qhalf, f2);
+        } else {
+#pragma unroll
+          for (int e = 0; e < E; ++e) x[e] = lift(op ? v1[e] : v0[e], pc);
+        }
+        wave_fwd<LOGN>(x, ln, lds, twf, pc);
+        uint4* __restrict__ dst = op ? XL : P4;   // (generic store: LDS for the first operand, scratch line for the last)
+        if (op) {
+#pragma unroll
+          for (int g = 0; g < E / 4; ++g) XL[g * 64 + ln] = make_uint4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
+        } else {
+#pragma unroll
+          for (int g = 0; g < E / 4; ++g) P4[g * 64 + ln] = make_uint4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
+        }
+        (void)dst;
+      }
+      const int nimg = mode == SHORT_SPLIT ? 2 : 1;
+      const int img0 = mode == SHORT_SPLIT ? kImgLo : pp;
+#pragma unroll 1
+      for (uint32_t r = 0; r < (pair ? 2u : 1u); ++r) {
+        uint32_t u[E];   // SPLIT: the low half's integers first (int32 bits); in the end the row's value mod q
+#pragma unroll 1
+        for (int k = 0; k < nimg; ++k) {
+          RZK_STEP_PRIORITY();
+          const int img = img0 + k;
+          int li = lane;
+          RZK_OPAQUE(li);
+          uint32_t sacc[E];
+#pragma unroll
+          for (int c = 0; c < E; ++c) sacc[c] = 0;
+          if (r == 0 && nit == 2 && i0.keyA != kNoKey)
+            mac_key<LOGN, true>(sacc, nullptr, const_cast<const uint4*>(P4),
+                                reinterpret_cast<const uint4*>(key_ntt + ((size_t)i0.keyA * kKeyImages + img) * N), i0.signA < 0, li, pc);
+          const uint16_t kent = r ? i1.keyB : i1.keyA;
+          if (kent != kNoKey)
+            mac_key<LOGN, true>(sacc, nullptr, const_cast<const uint4*>(XL),
+                                reinterpret_cast<const uint4*>(key_ntt + ((size_t)kent * kKeyImages + img) * N),
+                                (r ? i1.signB : i1.signA) < 0, li, pc);
+          if (mode == SHORT_SPLIT && k == 1) {   // P is free now (row A's parked transform has been used): the low half's
+#pragma unroll                                    // integers wait there during the transform
+            for (int g = 0; g < E / 4; ++g) P4[g * 64 + li] = make_uint4(u[4 * g], u[4 * g + 1], u[4 * g + 2], u[4 * g + 3]);
+          }
+          uint4 sa[E / 4], sb[E / 4];
+          if (mode == SHORT_THREE) {   // Garner words of the row, requested before the transform
+            const uint4* __restrict__ A4 = reinterpret_cast<const uint4*>(st + (size_t)(2 * r) * N);
+            const uint4* __restrict__ B4 = reinterpret_cast<const uint4*>(st + (size_t)(2 * r + 1) * N);
+#pragma unroll
+            for (int g = 0; g < E / 4; ++g) sa[g] = A4[g * 64 + li], sb[g] = B4[g * 64 + li];
+          }
+          wave_inv<LOGN>(sacc, li, lds, twf + kTableLen, pc);
+          if (mode == SHORT_ONE) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) u[e] = crt_finish_zq(crt_fold0(sacc[e], 1, T.pc, T.crt), 1, T.crt);
+          } else if (mode == SHORT_THREE) {
+#pragma unroll
+            for (int g = 0; g < E / 4; ++g) {
+              uint32_t a[4] = {sa[g].x, sa[g].y, sa[g].z, sa[g].w};
+              const uint32_t bb[4] = {sb[g].x, sb[g].y, sb[g].z, sb[g].w};
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                crt_fold2(sacc[4 * g + i], T.pc, T.crt, a[i], bb[i]);
+                u[4 * g + i] = crt_finish_zq(a[i], 3, T.crt);
+              }
+            }
+          } else if (k == 0) {   // SPLIT, low half: residue mod p0 (lazy, [0,2p0)) -> the exact integer, |.| < 2^29
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+              const uint32_t dd = csub(sacc[e], pc.p);
+              u[e] = dd >= T.crt.half1 ? dd - pc.p : dd;   // (int32 bits)
+            }
+          } else {               // SPLIT, high half: value = lo + 2^16 hi (mod q), hi * 2^16 by one Montgomery step
+#pragma unroll
+            for (int g = 0; g < E / 4; ++g) {
+              const uint4 lv = P4[g * 64 + li];
+              const uint32_t ls[4] = {lv.x, lv.y, lv.z, lv.w};
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const uint32_t dd = csub(sacc[4 * g + i], pc.p);
+                const int32_t rr = (int32_t)(dd >= T.crt.half1 ? dd - pc.p : dd);
+                const uint32_t hi_q = montq_u(zq_from_centered(rr, T.crt.q), T.crt.r48q, T.crt);
+                u[4 * g + i] = addq(hi_q, zq_from_centered((int32_t)ls[i], T.crt.q), T.crt.q);
+              }
+            }
+          }
+        }
+        finish_row<LOGN>(u, prog, table_load(&prog->rows[r ? un.rowB : un.rowA]), ops, b, bo, lane, T, flags,
+                         (has_shift && r == 0) ? st_sh : nullptr);
+      }
+    }
+  }
+#undef RZK_STEP_PRIORITY
 }
 
 // =============================================================================================
@@ -1287,7 +1703,7 @@ row_group_kernel(const Program* __restrict__ prog, const Operands ops, const uin
               const Term tg = prog->terms[prog->rows[gd.row0 + g].term0 + t];
               if (first) bound[g] += key_inf[tg.a_off] * l1;
               const uint4* __restrict__ kp =
-                  reinterpret_cast<const uint4*>(key_ntt + ((size_t)tg.a_off * kMaxPrimes + pi) * N);
+                  reinterpret_cast<const uint4*>(key_ntt + ((size_t)tg.a_off * kKeyImages + pi) * N);
 #pragma unroll
               for (int q4 = 0; q4 < E / 4; ++q4) {
                 const uint4 kv = kp[q4 * 64 + ln];
@@ -1412,7 +1828,7 @@ row_block_kernel(const Program* __restrict__ prog, const BlockPlan* __restrict__
         for (uint32_t t = 0; t < row.nterms; ++t) {
           const Term tm = prog->terms[row.term0 + t];
           const uint32_t* __restrict__ xs = staged + (size_t)plan->term_slot[row.term0 + t] * N + lane;
-          const uint4* __restrict__ kp = reinterpret_cast<const uint4*>(key_ntt + ((size_t)tm.a_off * kMaxPrimes + pi) * N);
+          const uint4* __restrict__ kp = reinterpret_cast<const uint4*>(key_ntt + ((size_t)tm.a_off * kKeyImages + pi) * N);
 #pragma unroll
           for (int g = 0; g < E / 4; ++g) {
             const uint4 kv = kp[g * 64 + lane];
@@ -1575,7 +1991,7 @@ row_slots_kernel(const Program* __restrict__ prog, const SlotTable* __restrict__
             const uint4* __restrict__ other =
                 vec ? reinterpret_cast<const uint4*>(
                           ws + (((size_t)b * nslots + slots->term_a[row.term0 + t]) * np_store + pi) * N)
-                    : reinterpret_cast<const uint4*>(key_ntt + ((size_t)tm.a_off * kMaxPrimes + pi) * N);
+                    : reinterpret_cast<const uint4*>(key_ntt + ((size_t)tm.a_off * kKeyImages + pi) * N);
 #pragma unroll
             for (int g = 0; g < E / 4; ++g) {
               const uint4 xv = xb[g * 64 + lane];
@@ -1612,7 +2028,8 @@ row_slots_kernel(const Program* __restrict__ prog, const SlotTable* __restrict__
 }
 
 // =============================================================================================
-// Key transform: centred key entries -> NTT domain (x N^-1, Montgomery form) for all three primes
+// Key transform: centred key entries -> NTT domain (x N^-1, Montgomery form) for all three primes, plus the two
+// half images under prime 0 (rzk_core.h, kKeyImages)
 // =============================================================================================
 template <int LOGN>
 __global__ void __launch_bounds__(256)
@@ -1626,17 +2043,24 @@ key_transform_kernel(const int64_t* __restrict__ key, uint32_t entries, uint32_t
   const int lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t* lds = smem + wave * G::LDS_WORDS;
-  const uint32_t ntasks = entries * kMaxPrimes;
+  const uint32_t ntasks = entries * kKeyImages;
   for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
-    const uint32_t entry = task / kMaxPrimes;
-    const int pi = task % kMaxPrimes;
+    const uint32_t entry = task / kKeyImages;
+    const int img = task % kKeyImages;
+    const int pi = img < kMaxPrimes ? img : 0;   // the two half images live under prime 0
     const PrimeConsts pc = T.pc[pi];
     const int64_t* __restrict__ src = key + (uint64_t)entry * N;
     uint32_t x[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) x[e] = lift((int32_t)src[G::j_p1(lane, e)], pc);
+    for (int e = 0; e < E; ++e) {
+      const int32_t kv = (int32_t)src[G::j_p1(lane, e)];
+      // K = Klo + 2^16 Khi with Klo in [-2^15, 2^15) (so |Khi| <= 2^15 for every centred K)
+      const int32_t klo = (int32_t)(((uint32_t)kv + 0x8000u) & 0xffffu) - 0x8000;
+      const int32_t v = img == kImgLo ? klo : (img == kImgHi ? (kv - klo) >> kSplitShift : kv);
+      x[e] = lift(v, pc);
+    }
     wave_fwd<LOGN>(x, lane, lds, tw_all + (size_t)(2 * pi) * kTableLen, pc);
-    uint4* __restrict__ dst = reinterpret_cast<uint4*>(key_ntt + ((uint64_t)entry * kMaxPrimes + pi) * N);
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(key_ntt + ((uint64_t)entry * kKeyImages + img) * N);
 #pragma unroll
     for (int g = 0; g < E / 4; ++g) {
       uint4 v;
@@ -2091,7 +2515,7 @@ static inline unsigned grid_for(uint64_t tasks, int num_cus, int waves_per_block
     if (e_ != hipSuccess) return (int)e_;       \
   } while (0)
 
-size_t row_scratch_words(int logn, int num_cus) { return (size_t)num_cus * 8 * 4 * (((size_t)5 << logn) + 16); }
+size_t row_scratch_words(int logn, int num_cus) { return (size_t)num_cus * 8 * 4 * (((size_t)kScratchLines << logn) + 16); }
 
 template <int LOGN, bool HAS_VEC, bool HAS_SHIFT>
 static int launch_units_t(const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, const Operands& ops,
@@ -2113,6 +2537,45 @@ static int launch_units_t(const LaunchCfg& cfg, const Program* d_prog, const Wav
                      d_wp, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks, upt, tpe, wpt);
   RZK_LAUNCH_CHECK();
   return 0;
+}
+
+template <int LOGN, bool HAS_SHIFT>
+static int launch_short_t(const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, const Operands& ops,
+                          const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T, const uint32_t* d_tw,
+                          uint32_t* d_scratch, uint8_t* d_flags, uint32_t ntasks, uint32_t upt, uint32_t tpe, uint32_t wpt,
+                          uint32_t allow_split) {
+  using G = Geo<LOGN>;
+  const size_t lds = 4 * (size_t)(G::LDS_WORDS + G::N) * sizeof(uint32_t);   // per wave: transposition slab + P
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&short_kernel<LOGN, HAS_SHIFT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const unsigned grid = grid_for(ntasks, cfg.num_cus, 4, 8);   // <= num_cus * 8 blocks (scratch sizing)
+  hipLaunchKernelGGL((short_kernel<LOGN, HAS_SHIFT>), dim3(grid), dim3(256), lds, (hipStream_t)cfg.stream, d_prog, d_wp, ops,
+                     d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks, upt, tpe, wpt, allow_split);
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_short(int logn, const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, uint32_t nunits,
+                 uint32_t units_per_task, uint32_t work_per_entry, bool has_shift, bool allow_split, const Operands& ops,
+                 const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T, const uint32_t* d_tw,
+                 uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch) {
+  if (batch == 0 || nunits == 0) return 0;
+  if (units_per_task == 0) units_per_task = 1;
+  const uint32_t tpe = (nunits + units_per_task - 1) / units_per_task;
+  if (batch * tpe >= (1ull << 32)) return -2;
+  const uint32_t ntasks = (uint32_t)(batch * tpe);
+  const uint32_t wpt = (work_per_entry + tpe - 1) / tpe;
+#define RZK_SHORT_ARGS cfg, d_prog, d_wp, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks, units_per_task, tpe, wpt, allow_split ? 1u : 0u
+  switch (logn) {
+    case 9: return has_shift ? launch_short_t<9, true>(RZK_SHORT_ARGS) : launch_short_t<9, false>(RZK_SHORT_ARGS);
+    case 10: return has_shift ? launch_short_t<10, true>(RZK_SHORT_ARGS) : launch_short_t<10, false>(RZK_SHORT_ARGS);
+    case 11: return has_shift ? -1 : launch_short_t<11, false>(RZK_SHORT_ARGS);
+  }
+#undef RZK_SHORT_ARGS
+  return -1;
 }
 
 int launch_units(int logn, const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, uint32_t nunits,
@@ -2278,7 +2741,7 @@ static int launch_key_t(const LaunchCfg& cfg, const int64_t* d_key, uint32_t ent
                         const DevTables* T, const uint32_t* d_tw) {
   using G = Geo<LOGN>;
   const size_t lds = 4 * G::LDS_WORDS * sizeof(uint32_t);
-  const unsigned grid = grid_for((uint64_t)entries * kMaxPrimes, cfg.num_cus);
+  const unsigned grid = grid_for((uint64_t)entries * kKeyImages, cfg.num_cus);
   hipLaunchKernelGGL(key_transform_kernel<LOGN>, dim3(grid), dim3(256), lds, (hipStream_t)cfg.stream,
                      d_key, entries, d_key_ntt, T, d_tw);
   RZK_LAUNCH_CHECK();

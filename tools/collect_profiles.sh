@@ -14,3 +14,4 @@ w=$(find $out/${tag}_pmc_write -name "*counter_collection.csv" | head -1)
 python3 tools/pmc_traffic.py "$f" "$w" $out/${tag}_pmc_row_kernel.json > /dev/null
 grep -E "rzk::" $(find $out/${tag}_trace -name "*kernel_stats.csv" | head -1) | head -8
 python3 -c "import json; j=json.load(open('$out/${tag}_pmc_row_kernel.json')); print('traffic/alg', j['traffic_over_algorithmic'], 'bytes/launch', j['hbm_bytes_per_launch'])"
+grep -E "row_kernel|unit_kernel" $(find $out/${tag}_trace -name "*kernel_stats.csv" | head -1) > /dev/null && cp $(find $out/${tag}_trace -name "*kernel_stats.csv" | head -1) $out/${tag}_kernel_stats_bench_open1024.csv

@@ -38,14 +38,21 @@ def main():
     cal_norm = (B * K * N * 8) / fetch[norm_keys[0]] if norm_keys else cal_ntt
     wr_check = write[ntt_key] / (NTT_POLYS * N * 4)
     rows = {}
+    per_phase = {}
+    alg = {"commit": 10, "response": 10, "verify": 6}   # polynomials of 8*N bytes a phase moves at the boundary
     for k in fetch:
-        if "row_kernel" in k[0]:
+        if "row_kernel" in k[0] or "unit_kernel" in k[0]:
+            phase = "response" if "shift_row_kernel" in k[0] else ("verify" if k[0].rstrip(">").endswith("true") else "commit")
             rows[f"{k[0]} grid={k[1]}"] = {
+                "phase": phase,
                 "launches": nf[k],
                 "fetch_bytes_raw": fetch[k],
                 "fetch_bytes_corrected": fetch[k] * cal_norm,
                 "write_bytes": write.get(k, 0.0),
+                "algorithmic_bytes": alg[phase] * 8 * N * B,
             }
+            rows[f"{k[0]} grid={k[1]}"]["traffic_over_algorithmic"] = (fetch[k] * cal_norm + write.get(k, 0.0)) / (alg[phase] * 8 * N * B)
+            per_phase[phase] = fetch[k] * cal_norm + write.get(k, 0.0)
     total = sum(v["fetch_bytes_corrected"] + v["write_bytes"] for v in rows.values())
     out = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py --steps 3",
@@ -55,10 +62,11 @@ def main():
         "write_size_over_known_bytes_ntt_fwd": wr_check,
         "row_kernel_launches_per_cycle": rows,
         "hbm_bytes_per_cycle": total,
-        "hbm_bytes_per_launch": total / max(len(rows), 1),
+        "hbm_bytes_per_launch": per_phase,
+        "hbm_bytes_per_launch_mean": total / max(len(rows), 1),
         "algorithmic_bytes_per_launch": 26 * 8 * N * B / 3.0,
     }
-    out["traffic_over_algorithmic"] = out["hbm_bytes_per_launch"] / out["algorithmic_bytes_per_launch"]
+    out["traffic_over_algorithmic"] = out["hbm_bytes_per_launch_mean"] / out["algorithmic_bytes_per_launch"]
     text = json.dumps(out, indent=1)
     print(text)
     if len(sys.argv) > 3:

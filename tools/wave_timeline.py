@@ -42,8 +42,8 @@ tot = C.c_size_t(0)
 ctx._L.rzk_debug_read_scratch(ctx._h, None, 0, C.byref(tot))
 buf = np.empty(tot.value // 4, dtype=np.uint32)
 ctx._L.rzk_debug_read_scratch(ctx._h, C.c_void_p(buf.ctypes.data), tot.value, None)
-stride = 5 * N + 16
-lines = buf.reshape(-1, stride)[:, 5 * N:5 * N + 16]
+stride = 6 * N + 16
+lines = buf.reshape(-1, stride)[:, 6 * N:6 * N + 16]
 lines = lines[:B]   # one wave per proof: blocks 0..1023
 t0 = lines[:, 0].astype(np.uint64) | (lines[:, 1].astype(np.uint64) << 32)
 t1 = lines[:, 2].astype(np.uint64) | (lines[:, 3].astype(np.uint64) << 32)

@@ -59,7 +59,7 @@ struct DevProg {
   WaveProgram* d_wp = nullptr;   // units / items of unit_kernel (the default path)
   uint32_t nunits = 0;
   uint32_t work = 0;             // steps (item + inverse trips) of one batch entry per prime pass
-  bool all_short = false;        // every unit is short (<= 2 key items, no vector x vector item): short_kernel
+  uint32_t nsplit = 0;           // units that are candidates for split_kernel
   bool has_vec = false;
   // shared-operand path (fwd_slots_kernel + row_slots_kernel), chosen when rows share enough operands
   SlotTable* d_slots = nullptr;
@@ -98,8 +98,8 @@ struct rzk_ctx {
   uint32_t block_min_logn = 11;        // row blocks from this ring degree on (below it row groups do the sharing)
   bool use_groups = true;
   uint32_t units_per_task = 0;         // 0 = automatic (RZK_UPT overrides, tuning)
-  bool use_short = true;               // short_kernel for programs made of short units (RZK_SHORT=0 turns it off, tuning)
-  bool use_split = true;               // short_kernel: split evaluation for small-norm operands (RZK_SPLIT=0, tuning)
+  bool use_split = false;              // split_kernel for key products with small-norm operands: measured slower than
+                                       // unit_kernel's two-prime pairs; RZK_SPLIT=1 turns it on
   bool use_pairs = true;               // unit_kernel: pair rows that share their last operand (RZK_PAIRS=0 turns it off, tuning)
   int group_max = 1;                   // rows per group of row_group_kernel (group_max_for; RZK_GROUP_MAX overrides, tuning)
   bool use_shift = true;               // challenge products as signed rotations (shift_row_kernel) instead of transforms
@@ -114,7 +114,7 @@ struct rzk_ctx {
   uint32_t* d_key_ntt = nullptr;
   double* d_key_inf = nullptr;
   std::map<std::pair<int, uint32_t>, DevProg> progs;
-  Arena ws, stage, ws_slots;
+  Arena ws, stage, ws_slots, ws_done;
   // canonical-input test (rzk_dev.h, Operands::bad): sticky word set by any kernel that loaded a coefficient
   // outside the centred range on behalf of an entry point without per-proof verdicts; read back at every
   // synchronising call (host-pointer variants, rzk_ctx_synchronize, rzk_ctx_check_inputs)
@@ -184,6 +184,7 @@ struct PB {
   bool overflow = false;
   bool two_bit = false;      // the program carries CHECK2 marks: two-bit verdict flags (row_kernel only)
   uint32_t sparse_ops = 0;   // bit i: operand i is a challenge (kappa-sparse, +-1): products with it may use shift-add
+  uint32_t small_ops = 0;    // bit i: operand i is expected to have a small 1-norm (commitment randomness): split_kernel
   int cur = -1;
   void begin_row(uint8_t out_op, uint32_t out_off, uint8_t mode) {
     if (p.nrows >= (uint32_t)kMaxRows) { overflow = true; return; }
@@ -324,6 +325,7 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
       }
       break;
     case PG_OPEN_COMMIT:   // ops: 0 = x[l], 1 = r[k], 2 = y[k], 3 = c[n+l], 4 = t[n]
+      pb.small_ops = 1u << 1;
       for (uint32_t i = 0; i < n + l; ++i) {   // commit.rs:125: c = [a1;a2].r + [0_n ; x]
         pb.begin_row(3, i, MODE_STORE);
         key_row(c, pb, +1, i, 1, 0);
@@ -338,6 +340,7 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
       }
       break;
     case PG_COMMIT:   // ops: 0 = x[l], 1 = r[k], 2 = c[n+l]
+      pb.small_ops = 1u << 1;
       for (uint32_t i = 0; i < n + l; ++i) {   // commit.rs:109-125
         pb.begin_row(2, i, MODE_STORE);
         key_row(c, pb, +1, i, 1, 0);
@@ -348,6 +351,7 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
       }
       break;
     case PG_COMMIT_VERIFY:   // ops: 0 = x[l], 1 = r[k], 2 = c[n+l], 3 = f ; flags &= (commit.rs:199-209)
+      if (!(var & 2)) pb.small_ops = 1u << 1;
       for (uint32_t i = 0; i < n + l; ++i) {
         pb.begin_row(0, 0, MODE_ZERO);
         key_row(c, pb, +1, i, 1, 0);
@@ -406,6 +410,7 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
     case PG_LIN_COMMIT2:
       // ops: 0 = x[l], 1 = gx[l], 2 = r[k], 3 = rp[k], 4 = y[k], 5 = yp[k],
       //      6 = c[n+l], 7 = cp[n+l], 8 = t[n], 9 = tp[n], 10 = a2y[l]
+      pb.small_ops = (1u << 2) | (1u << 3);
       for (uint32_t i = 0; i < n + l; ++i) {   // linear.rs:97: c = commit(x; r)
         pb.begin_row(6, i, MODE_STORE);
         key_row(c, pb, +1, i, 2, 0);
@@ -688,11 +693,20 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
           }
         }
       }
-      if (ra.nterms <= 2 && key_only(ra)) un.nitems |= kUnitShort;
+      // split candidates: one or two key products, every operand hinted small, no rotation terms (those use the
+      // st_sh scratch line protocol of unit_kernel)
+      if (c->use_split && ra.nterms >= 1 && ra.nterms <= 2 && ra.nshift == 0 && key_only(ra) &&
+          (un.rowB == kNoRow || pb.p.rows[r + 1].nshift == 0)) {
+        bool small = true;
+        for (uint32_t t = 0; t < ra.nterms; ++t) small = small && ((pb.small_ops >> pb.p.terms[ra.term0 + t].b_op) & 1u);
+        if (small) {
+          wp.split_units[wp.nsplit++] = (uint16_t)(wp.nunits - 1);
+          un.nitems |= kUnitSplit;
+        }
+      }
       r += step;
     }
-    dp.all_short = wp.nunits > 0;
-    for (uint32_t u = 0; u < wp.nunits; ++u) dp.all_short = dp.all_short && (wp.units[u].nitems & kUnitShort);
+    dp.nsplit = wp.nsplit;
     HIPCHK(c, hipMalloc((void**)&dp.d_wp, sizeof(WaveProgram)));
     HIPCHK(c, hipMemcpyAsync(dp.d_wp, &wp, sizeof(WaveProgram), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -840,12 +854,17 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
     // the chip's wave slots; one unit per task below that
     uint32_t upt = batch >= (uint64_t)c->num_cus * 16 ? dp.nunits : 1;
     if (c->units_per_task) upt = c->units_per_task;   // RZK_UPT (tuning)
-    if (dp.all_short && c->use_short)
-      lrc = launch_short((int)c->logn, cfg_of(c), dp.d, dp.d_wp, dp.nunits, upt, 2 * dp.work + dp.nunits, dp.has_shift, c->use_split,
-                         ops, c->d_key_ntt, c->d_key_inf, c->dT, c->d_tw, c->d_row_scratch, flags, batch);
-    else
+    uint8_t* d_done = nullptr;
+    if (dp.nsplit) {   // small-norm operands first (split_kernel marks what it finished), everything else after
+      int rc2 = arena_reserve(c, c->ws_done, (size_t)batch * dp.nunits);
+      if (rc2 != RZK_OK) return rc2;
+      d_done = (uint8_t*)c->ws_done.p;
+      lrc = launch_split((int)c->logn, cfg_of(c), dp.d, dp.d_wp, dp.nsplit, ops, c->d_key_ntt, c->d_key_inf, c->dT, c->d_tw,
+                         c->d_row_scratch, flags, d_done, batch);
+    }
+    if (lrc == 0)
       lrc = launch_units((int)c->logn, cfg_of(c), dp.d, dp.d_wp, dp.nunits, upt, 2 * dp.work, dp.has_vec, dp.has_shift, ops,
-                         c->d_key_ntt, c->d_key_inf, c->dT, c->d_tw, c->d_row_scratch, flags, batch);
+                         c->d_key_ntt, c->d_key_inf, c->dT, c->d_tw, c->d_row_scratch, flags, batch, d_done);
   }
   if (lrc == -2) return fail(c, RZK_E_UNSUPPORTED, "batch * rows must stay below 2^32");
   if (lrc != 0) {
@@ -1019,7 +1038,6 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
   if (const char* e = std::getenv("RZK_SHIFT")) c->use_shift = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_PAIRS")) c->use_pairs = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_UPT")) c->units_per_task = (uint32_t)std::atoi(e);
-  if (const char* e = std::getenv("RZK_SHORT")) c->use_short = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_SPLIT")) c->use_split = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_BLOCK_MIN_LOGN")) c->block_min_logn = (uint32_t)std::atoi(e);   // 12 = never
 
@@ -1065,6 +1083,7 @@ void rzk_ctx_destroy(rzk_ctx* c) {
   if (c->d_key_inf) (void)hipFree(c->d_key_inf);
   if (c->ws.p) (void)hipFree(c->ws.p);
   if (c->ws_slots.p) (void)hipFree(c->ws_slots.p);
+  if (c->ws_done.p) (void)hipFree(c->ws_done.p);
   if (c->stage.p) (void)hipFree(c->stage.p);
   if (c->dT) (void)hipFree(c->dT);
   if (c->d_tw) (void)hipFree(c->d_tw);

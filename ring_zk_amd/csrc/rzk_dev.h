@@ -120,16 +120,18 @@ struct alignas(8) Item {
   int8_t signA, signB;
   uint16_t pad;
 };
-constexpr uint16_t kUnitShort = 0x8000;       // in Unit::nitems: key products over at most two operands (short_kernel)
+constexpr uint16_t kUnitSplit = 0x8000;       // in Unit::nitems: candidate for split_kernel (<= 2 key items, operands hinted small)
 constexpr uint16_t kUnitItemsMask = 0x7fff;
 struct alignas(8) Unit {
   uint16_t rowA, rowB;      // indices into Program::rows; rowB = kNoRow for a single row
-  uint16_t item0, nitems;   // nitems & kUnitItemsMask items from item0 on; kUnitShort flag
+  uint16_t item0, nitems;   // nitems & kUnitItemsMask items from item0 on; kUnitSplit flag
 };
 struct WaveProgram {
   uint32_t nunits, nitems;
+  uint32_t nsplit, pad;
   Unit units[kMaxRows];
   Item items[kMaxTerms];
+  uint16_t split_units[kMaxRows];   // indices of the split candidates
 };
 
 // Shared-operand path: the distinct polynomials ("slots") the product terms of a program read, and for
@@ -184,17 +186,15 @@ struct LaunchCfg {
 
 // units_per_task: how many consecutive units of one batch entry a wavefront evaluates back to back (all of them =
 // one wavefront per proof: equal-cost tasks, no tail)
-// Programs whose units are all short (<= 2 key items per row, pairs allowed): short_kernel — every operand loaded once,
-// one-prime / split / two-prime-interleaved evaluation chosen per unit from the operands' norms (rzk_kernels.hip)
-int launch_short(int logn, const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, uint32_t nunits,
-                 uint32_t units_per_task, uint32_t work_per_entry, bool has_shift, bool allow_split, const Operands& ops,
-                 const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* d_T, const uint32_t* d_tw,
-                 uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch);
+// split_kernel over the program's split candidates; done[b * nunits + unit] = 1 for the units it finished
+int launch_split(int logn, const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, uint32_t nsplit,
+                 const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* d_T,
+                 const uint32_t* d_tw, uint32_t* d_scratch, uint8_t* d_flags, uint8_t* d_done, uint64_t batch);
 // work_per_entry: transforms one batch entry costs at two primes (the progress priorities only need an estimate)
 int launch_units(int logn, const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, uint32_t nunits,
                  uint32_t units_per_task, uint32_t work_per_entry, bool has_vec, bool has_shift, const Operands& ops,
                  const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* d_T, const uint32_t* d_tw,
-                 uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch);
+                 uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch, const uint8_t* d_done = nullptr);
 int launch_row_program_slots(int logn, const LaunchCfg& cfg, const Program* d_prog, const SlotTable* d_slots,
                              uint32_t nslots, const Operands& ops, const uint32_t* d_key_ntt,
                              const double* d_key_inf, const DevTables* d_T, const uint32_t* d_tw, uint32_t* d_ws,

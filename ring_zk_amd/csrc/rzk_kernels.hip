@@ -228,6 +228,7 @@ __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict
 
 // ---- challenge products as signed rotations (ShiftGeo, rzk_core.h): shared by shift_row_kernel and the
 // shift terms of row_kernel ---------------------------------------------------------------------------------
+
 template <int LOGN>
 __device__ __forceinline__ void load_pairs(int32_t* v, const int64_t* __restrict__ src, int lane, uint32_t qhalf,
                                            uint32_t& bad, uint32_t& mx) {
@@ -765,7 +766,7 @@ __device__ __forceinline__ bool inverse_fold_global(int pi, int np, uint32_t* ac
 // u[e] = the row's product sum mod q (coefficient e*64 + lane; zero when the row has no products): adds the sum of
 // the row's rotation terms (st_sh, left in the wave's scratch line by the same lanes), the plain additions, then
 // store / zero test, norm marks of checked additions, canonical-input test of everything loaded.
-template <int LOGN>
+template <int LOGN, int CHMAX = 16>
 __device__ __forceinline__ void finish_row(uint32_t* u, const Program* __restrict__ prog, const Row row,
                                            const Operands& ops, uint32_t b, uint32_t bo, int lane, const DevTables& T,
                                            uint8_t* __restrict__ flags, const uint32_t* __restrict__ st_sh) {
@@ -779,7 +780,7 @@ __device__ __forceinline__ void finish_row(uint32_t* u, const Program* __restric
   }
   // An addition is loaded with up to 16 of a lane's coefficients in flight (a row's wall time is dominated by how
   // often it waits for HBM; 16 sixty-four-bit values are what the register budget of 4 waves per SIMD leaves room for).
-  constexpr int CH = E < 16 ? E : 16;
+  constexpr int CH = E < CHMAX ? E : CHMAX;
   uint64_t add_sq[4] = {0, 0, 0, 0};
   uint32_t in_bad = 0, in_mx = 0;
   int nz = 0;
@@ -857,7 +858,7 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
             const uint32_t* __restrict__ key_ntt, const double* __restrict__ key_inf, const DevTables* __restrict__ Tp,
             const uint32_t* __restrict__ tw_all, uint32_t* __restrict__ scratch, uint8_t* __restrict__ flags,
             const uint32_t ntasks, const uint32_t units_per_task, const uint32_t tasks_per_entry,
-            const uint32_t work_per_task) {
+            const uint32_t work_per_task, const uint8_t* __restrict__ done) {
   using G = Geo<LOGN>;
   constexpr int E = G::E;
   constexpr int N = G::N;
@@ -924,7 +925,8 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
       const Unit un = table_load(&wp->units[ui]);
       const Row rowA = table_load(&prog->rows[un.rowA]);
       const bool pair = un.rowB != kNoRow;
-      const uint32_t un_items = un.nitems & kUnitItemsMask;   // (the kUnitShort flag rides in the same field)
+      if (done && (un.nitems & kUnitSplit) && done[(size_t)b * nunits + ui]) continue;   // finished by split_kernel
+      const uint32_t un_items = un.nitems & kUnitItemsMask;   // (the kUnitSplit flag rides in the same field)
       const bool null_unit = un_items == 0;   // no products: additions / rotation terms only
       const bool has_shift = HAS_SHIFT && rowA.nshift > 0;
       if (has_shift) {
@@ -1106,21 +1108,18 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
 }
 
 // =============================================================================================
-// short_kernel: programs whose units are all SHORT — key products over at most two operands per row, optionally a
-// pair (rzk_dev.h) — which is every key-product program of the (1,3,1) parameter family: the commitment rows, t = a1.y,
-// the verifier relation a1.z - c1 (.) d - t, a2.v ...  One wavefront per unit, and every operand is loaded ONCE:
-// both operands' raw low words sit in registers while their norms decide, before any transform, how the exact
-// integer products are obtained:
-//   ONE    bound <= cap(1 prime): one pass under prime 0;
-//   SPLIT  operands of small 1-norm (2^15 * sum |v|_1 <= cap(1 prime): the ternary randomness of a commitment): one
-//          pass under prime 0 against the two 16-bit HALVES of the key entries (rzk_core.h, kKeyImages), value =
-//          lo + 2^16 hi — one forward transform per operand instead of two, no Garner step;
-//   TWO    both primes interleaved per operand (transform under p0, then under p1, from the same registers): row A's
-//          p0-sum waits in P, its p1-sum in registers, the two residues meet in registers — no Garner state in memory;
-//   THREE  TWO, whose result becomes the Garner words (scratch line), then a third pass under prime 2 (operands re-read).
-// In the single-pass modes the transforms wait in P (first operand) and in the wave's scratch line (last operand) while
-// the rows' sums are formed and transformed back one after the other, so that only the accumulator is live during a
-// transform.  Boundary traffic of an Open commit: 7 polynomials in, 3 out — the algorithmic minimum.
+// split_kernel: key products whose operands have a SMALL 1-norm — the ternary randomness r of every commitment
+// (commit.rs:98-107: c = [a1;a2].r + [0;x] is a third of all transforms of an Open cycle).  With the key entries
+// available as two 16-bit halves under prime 0 (rzk_core.h, kKeyImages), K (*) v fits ONE prime per half whenever
+// 2^15 * sum_j |v_j|_1 <= (p0 - 1) / 2, so a unit (one row, or a pair sharing its last operand) needs one forward
+// transform per operand instead of two, no second pass over the operands and no Garner step:
+//     value = lo + 2^16 hi  with  lo = sum Klo_j (*) v_j,  hi = sum Khi_j (*) v_j   (exact integers, |.| < 2^29).
+// The host launches this kernel for the units it EXPECTS to qualify (operands hinted small by the program builder);
+// whether a unit does is decided here, per proof, from the measured norms (so results are exact for every input).  A
+// unit that qualifies is finished here and marked in `done`; unit_kernel, launched next, skips marked units and
+// evaluates all others the general way.  Both operands are loaded once (raw low words in registers); the transforms
+// wait in P (first operand) and in the wave's scratch line (last operand) while the rows' half-sums are formed and
+// transformed back one after the other; the low half's integers wait in P during the high half's transform.
 // =============================================================================================
 template <int LOGN>
 __device__ __forceinline__ void load_raw(int32_t* v, const int64_t* __restrict__ src, int lane, uint32_t qhalf, double& l1,
@@ -1150,29 +1149,6 @@ __device__ __forceinline__ void load_raw(int32_t* v, const int64_t* __restrict__
       sq += (uint64_t)a * a;
     }
     sumsq = wave_sum_u64(sq);
-  }
-}
-
-// P (+/-)= KEY image (*) x   (row A's running sum under one prime, parked in LDS)
-template <int LOGN>
-__device__ __forceinline__ void mac_into_P(const uint32_t* x, const uint4* __restrict__ kp, bool minus, uint4* P4, int lane,
-                                           bool init, const PrimeConsts& pc) {
-  constexpr int E = Geo<LOGN>::E;
-#pragma unroll
-  for (int g = 0; g < E / 4; ++g) {
-    const uint4 kv = kp[g * 64 + lane];
-    const uint32_t ks[4] = {kv.x, kv.y, kv.z, kv.w};
-    uint4 a = make_uint4(0, 0, 0, 0);
-    if (!init) a = P4[g * 64 + lane];
-    uint32_t as[4] = {a.x, a.y, a.z, a.w};
-    if (minus) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) as[i] = mac_sub(as[i], x[4 * g + i], ks[i], pc);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) as[i] = mac_add(as[i], x[4 * g + i], ks[i], pc);
-    }
-    P4[g * 64 + lane] = make_uint4(as[0], as[1], as[2], as[3]);
   }
 }
 
@@ -1206,15 +1182,12 @@ __device__ __forceinline__ void mac_key(uint32_t* acc, const uint32_t* x, XP X4,
   else mac_key_signed<LOGN, FROM_MEM, false>(acc, x, X4, kp, lane, pc);
 }
 
-enum : int { SHORT_ONE = 0, SHORT_SPLIT = 1, SHORT_TWO = 2, SHORT_THREE = 3 };
-
-template <int LOGN, bool HAS_SHIFT>
+template <int LOGN>
 __global__ void __launch_bounds__(256)
-short_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp, const Operands ops,
+split_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp, const Operands ops,
              const uint32_t* __restrict__ key_ntt, const double* __restrict__ key_inf, const DevTables* __restrict__ Tp,
              const uint32_t* __restrict__ tw_all, uint32_t* __restrict__ scratch, uint8_t* __restrict__ flags,
-             const uint32_t ntasks, const uint32_t units_per_task, const uint32_t tasks_per_entry,
-             const uint32_t work_per_task, const uint32_t allow_split) {
+             uint8_t* __restrict__ done, const uint32_t ntasks) {
   using G = Geo<LOGN>;
   constexpr int E = G::E;
   constexpr int N = G::N;
@@ -1224,298 +1197,123 @@ short_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ w
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t* lds = smem + wave * (G::LDS_WORDS + N);             // transposition slab, then P
   uint4* P4 = reinterpret_cast<uint4*>(lds + G::LDS_WORDS);
-  // per-wave global scratch: [0,4N) Garner words [row A | B][word A | B] (rows B's lines double as its parked sums in
-  // mode TWO), [4N,5N) sum of row A's rotation terms, [5N,6N) the last operand's transform of the single-pass modes
   uint32_t* st = scratch + ((size_t)blockIdx.x * 4 + wave) * (size_t)(kScratchLines * N + 16);
-  uint32_t* st_sh = st + 4 * N;
-  uint4* XL = reinterpret_cast<uint4*>(st + 5 * N);
+  uint4* XL = reinterpret_cast<uint4*>(st + 5 * N);             // the last operand's transform
   const DevTables& T = *Tp;
   const uint32_t qhalf = T.crt.qhalf;
-  const uint32_t nunits = wp->nunits;
-  const uint32_t first_task = blockIdx.x * 4 + wave;
-  const uint32_t my_tasks = first_task < ntasks ? (ntasks - first_task + gridDim.x * 4 - 1) / (gridDim.x * 4) : 0;
-  const uint32_t work_total = my_tasks * work_per_task;
-  uint32_t work_done = 0;
-#define RZK_STEP_PRIORITY()                         \
-  do {                                              \
-    set_progress_priority(work_done, work_total);   \
-    ++work_done;                                    \
-  } while (0)
+  const uint32_t nunits = wp->nunits, nsplit = wp->nsplit;
+  const PrimeConsts pc = T.pc[0];
+  const uint32_t* __restrict__ twf = tw_all;
 
-  for (uint32_t task = first_task; task < ntasks; task += gridDim.x * 4) {
-    const uint32_t b = task / tasks_per_entry;
-    const uint32_t u0 = (task - b * tasks_per_entry) * units_per_task;
-    const uint32_t u1 = u0 + units_per_task < nunits ? u0 + units_per_task : nunits;
+  for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
+    const uint32_t b = task / nsplit;
+    const uint32_t ui = wp->split_units[task - b * nsplit];
     const uint32_t bo = ops.group > 1 ? b / ops.group : b;
-#pragma unroll 1
-    for (uint32_t ui = u0; ui < u1; ++ui) {
-      const Unit un = table_load(&wp->units[ui]);
-      const Row rowA = table_load(&prog->rows[un.rowA]);
-      const bool pair = un.rowB != kNoRow;
-      const uint32_t nit = un.nitems & kUnitItemsMask;   // 0 (additions / rotations only), 1 or 2
-      const bool has_shift = HAS_SHIFT && rowA.nshift > 0;
-      bool fault = false;
-      if (has_shift) {
-        // challenge products first (rotations, image in slab + P); their sum mod q waits in the wave's scratch line
-#pragma unroll 1
-        for (uint32_t t = 0; t < rowA.nshift; ++t) {
-          const Term tm = table_load(&prog->terms[rowA.term0 + rowA.nterms + t]);
-          const int64_t* __restrict__ pa = operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N);
-          int32_t a[E];
-          uint32_t abad = 0, amx = 0;
+    const Unit un = table_load(&wp->units[ui]);
+    const bool pair = un.rowB != kNoRow;
+    const uint32_t nit = un.nitems & kUnitItemsMask;   // 1 or 2
+    const Item i1 = table_load(&wp->items[un.item0 + nit - 1]);   // the last operand (feeds row A and a pair's row B)
+    const Item i0 = table_load(&wp->items[un.item0]);             // nit == 2: the first operand (row A only)
+    // ---- both operands: raw low words into registers (one pass over HBM), canonical test, norms, norm marks
+    int32_t v0[E], v1[E];
+    double l10 = 0.0, l11 = 0.0;
+    bool fault = false;
+    {
+      uint64_t sq = 0;
+      if (nit == 2) {
+        const bool chk = (i0.flags & (TERM_CHECK | TERM_CHECK2)) != 0;
+        load_raw<LOGN>(v0, operand_ptr(ops, i0.b_op, i0.b_off, b, bo, N), lane, qhalf, l10, chk, sq, fault);
+        if (chk && sq >= ops.norm_limit && lane == 0) fail_check(flags + bo, ops.pad != 0, (i0.flags & TERM_CHECK2) != 0);
+      } else {
 #pragma unroll
-          for (int e = 0; e < E; ++e) a[e] = canon_lo_mx(pa[G::j_p1(lane, e)], qhalf, abad, amx);
-          fault = fault || canon_fail(abad, amx, qhalf);
-          shift_product<LOGN, false, true>(st_sh, t == 0, tm.sign < 0, a, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane,
-                                           reinterpret_cast<int32_t*>(lds), T, fault);
-        }
-        wave_sync();   // the image is dead: slab and P may be overwritten
+        for (int e = 0; e < E; ++e) v0[e] = 0;
       }
-      if (nit == 0) {
-        if (fault) input_fault(ops, flags, bo, lane);
-        uint32_t u[E];
-#pragma unroll
-        for (int e = 0; e < E; ++e) u[e] = 0;
-        finish_row<LOGN>(u, prog, rowA, ops, b, bo, lane, T, flags, has_shift ? st_sh : nullptr);
-        continue;
-      }
-      const Item i1 = table_load(&wp->items[un.item0 + nit - 1]);   // the last operand (feeds row A and a pair's row B)
-      const Item i0 = table_load(&wp->items[un.item0]);             // nit == 2: the first operand (row A only)
-      const int64_t* __restrict__ src0 = operand_ptr(ops, i0.b_op, i0.b_off, b, bo, N);
-      const int64_t* __restrict__ src1 = operand_ptr(ops, i1.b_op, i1.b_off, b, bo, N);
-      // ---- both operands: raw low words into registers (one pass over HBM), canonical test, norms, norm marks
-      int32_t v0[E], v1[E];
-      double l10 = 0.0, l11 = 0.0;
-      {
-        RZK_STEP_PRIORITY();
-        uint64_t sq = 0;
-        if (nit == 2) {
-          const bool chk = (i0.flags & (TERM_CHECK | TERM_CHECK2)) != 0;
-          load_raw<LOGN>(v0, src0, lane, qhalf, l10, chk, sq, fault);
-          if (chk && sq >= ops.norm_limit && lane == 0) fail_check(flags + bo, ops.pad != 0, (i0.flags & TERM_CHECK2) != 0);
-        } else {
-#pragma unroll
-          for (int e = 0; e < E; ++e) v0[e] = 0;
-        }
-        const bool chk1 = (i1.flags & (TERM_CHECK | TERM_CHECK2)) != 0;
-        load_raw<LOGN>(v1, src1, lane, qhalf, l11, chk1, sq, fault);
-        if (chk1 && sq >= ops.norm_limit && lane == 0) fail_check(flags + bo, ops.pad != 0, (i1.flags & TERM_CHECK2) != 0);
-      }
-      if (fault) input_fault(ops, flags, bo, lane);
-      const double boundA = (nit == 2 ? key_inf[i0.keyA] * l10 : 0.0) + (i1.keyA != kNoKey ? key_inf[i1.keyA] * l11 : 0.0);
-      const double boundB = pair ? key_inf[i1.keyB] * l11 : 0.0;
-      const int np = primes_for(boundA > boundB ? boundA : boundB, T);
-      int mode = np == 1 ? SHORT_ONE : (np == 2 ? SHORT_TWO : SHORT_THREE);
-      if (np == 2 && allow_split && 32768.0 * (l10 + l11) <= T.cap[1]) mode = SHORT_SPLIT;
-      mode = __builtin_amdgcn_readfirstlane(mode);
+      const bool chk1 = (i1.flags & (TERM_CHECK | TERM_CHECK2)) != 0;
+      load_raw<LOGN>(v1, operand_ptr(ops, i1.b_op, i1.b_off, b, bo, N), lane, qhalf, l11, chk1, sq, fault);
+      if (chk1 && sq >= ops.norm_limit && lane == 0) fail_check(flags + bo, ops.pad != 0, (i1.flags & TERM_CHECK2) != 0);
+    }
+    if (fault) input_fault(ops, flags, bo, lane);
+    const double boundA = (nit == 2 ? key_inf[i0.keyA] * l10 : 0.0) + (i1.keyA != kNoKey ? key_inf[i1.keyA] * l11 : 0.0);
+    const double boundB = pair ? key_inf[i1.keyB] * l11 : 0.0;
+    const int np = primes_for(boundA > boundB ? boundA : boundB, T);
+    const bool one = np == 1;                                               // one prime covers the whole product
+    const bool split = np == 2 && 32768.0 * (l10 + l11) <= T.cap[1];       // one prime per key half
+    const bool mine = __builtin_amdgcn_readfirstlane((one || split) ? 1 : 0) != 0;
+    if (lane == 0) done[(size_t)b * nunits + ui] = mine ? 1 : 0;
+    if (!mine) continue;   // unit_kernel evaluates this unit the general way
 
-      if (mode >= SHORT_TWO) {
-        // ---- both primes interleaved per operand; row A: p0-sum in P, p1-sum in registers; a pair's row B: scratch lines
-        uint32_t acc1[E];
-#pragma unroll
-        for (int c = 0; c < E; ++c) acc1[c] = 0;
+    // ---- forward transforms under prime 0: X1 -> P, X2 -> scratch line
 #pragma unroll 1
-        for (uint32_t op = 2 - nit; op < 2; ++op) {
-          const Item it = op ? i1 : i0;
-#pragma unroll 1
-          for (int p = 0; p < 2; ++p) {
-            RZK_STEP_PRIORITY();
-            const PrimeConsts pc = T.pc[p];
-            int ln = lane;
-            RZK_OPAQUE(ln);
-            uint32_t x[E];
+    for (uint32_t op = 2 - nit; op < 2; ++op) {
+      int ln = lane;
+      RZK_OPAQUE(ln);
+      uint32_t x[E];
 #pragma unroll
-            for (int e = 0; e < E; ++e) x[e] = lift(op ? v1[e] : v0[e], pc);
-            wave_fwd<LOGN>(x, ln, lds, tw_all + (size_t)(2 * p) * kTableLen, pc);
-            if (pair && op == 1) {   // row B's only product, parked in its scratch line for prime p
-              uint32_t accb[E];
+      for (int e = 0; e < E; ++e) x[e] = lift(op ? v1[e] : v0[e], pc);
+      wave_fwd<LOGN>(x, ln, lds, twf, pc);
+      if (op) {
 #pragma unroll
-              for (int c = 0; c < E; ++c) accb[c] = 0;
-              mac_key<LOGN, false>(accb, x, P4, reinterpret_cast<const uint4*>(key_ntt + ((size_t)it.keyB * kKeyImages + p) * N),
-                                   it.signB < 0, ln, pc);
-              uint4* __restrict__ BL = reinterpret_cast<uint4*>(st + (size_t)(2 + p) * N);
+        for (int g = 0; g < E / 4; ++g) XL[g * 64 + ln] = make_uint4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
+      } else {
 #pragma unroll
-              for (int g = 0; g < E / 4; ++g) BL[g * 64 + ln] = make_uint4(accb[4 * g], accb[4 * g + 1], accb[4 * g + 2], accb[4 * g + 3]);
-            }
-            if (it.keyA != kNoKey) {
-              const uint4* __restrict__ ka = reinterpret_cast<const uint4*>(key_ntt + ((size_t)it.keyA * kKeyImages + p) * N);
-              if (p == 0) mac_into_P<LOGN>(x, ka, it.signA < 0, P4, ln, op + nit == 2, pc);   // first contribution initialises
-              else mac_key<LOGN, false>(acc1, x, P4, ka, it.signA < 0, ln, pc);
-            } else if (p == 0 && op + nit == 2) {   // (row A without a product on its first operand: P starts at zero)
-#pragma unroll
-              for (int g = 0; g < E / 4; ++g) P4[g * 64 + ln] = make_uint4(0, 0, 0, 0);
-            }
-          }
-        }
-        // ---- residues of the two primes meet in registers
-#pragma unroll 1
-        for (uint32_t r = 0; r < (pair ? 2u : 1u); ++r) {
-          int li = lane;
-          RZK_OPAQUE(li);
-          if (r == 1) {
-            const uint4* __restrict__ BL = reinterpret_cast<const uint4*>(st + (size_t)3 * N);
-#pragma unroll
-            for (int g = 0; g < E / 4; ++g) {
-              const uint4 v = BL[g * 64 + li];
-              acc1[4 * g] = v.x, acc1[4 * g + 1] = v.y, acc1[4 * g + 2] = v.z, acc1[4 * g + 3] = v.w;
-            }
-          }
-          RZK_STEP_PRIORITY();
-          wave_inv<LOGN>(acc1, li, lds, tw_all + (size_t)(2 * 1 + 1) * kTableLen, T.pc[1]);
-          uint32_t acc0[E];
-          if (r == 0) {
-#pragma unroll
-            for (int g = 0; g < E / 4; ++g) {
-              const uint4 v = P4[g * 64 + li];
-              acc0[4 * g] = v.x, acc0[4 * g + 1] = v.y, acc0[4 * g + 2] = v.z, acc0[4 * g + 3] = v.w;
-            }
-          } else {
-            const uint4* __restrict__ BL = reinterpret_cast<const uint4*>(st + (size_t)2 * N);
-#pragma unroll
-            for (int g = 0; g < E / 4; ++g) {
-              const uint4 v = BL[g * 64 + li];
-              acc0[4 * g] = v.x, acc0[4 * g + 1] = v.y, acc0[4 * g + 2] = v.z, acc0[4 * g + 3] = v.w;
-            }
-          }
-          RZK_STEP_PRIORITY();
-          wave_inv<LOGN>(acc0, li, lds, tw_all + (size_t)(2 * 0 + 1) * kTableLen, T.pc[0]);
-          const int npc = mode == SHORT_TWO ? 2 : 3;
-          if (mode == SHORT_TWO) {
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-              const uint32_t d0 = crt_fold0(acc0[e], npc, T.pc, T.crt);
-              const uint32_t d1 = crt_digit1(acc1[e], d0, npc, T.pc, T.crt);
-              acc0[e] = crt_finish_zq(crt_value01_modq(d0, d1, T.crt), 2, T.crt);
-            }
-            finish_row<LOGN>(acc0, prog, table_load(&prog->rows[r ? un.rowB : un.rowA]), ops, b, bo, lane, T, flags,
-                             (has_shift && r == 0) ? st_sh : nullptr);
-          } else {   // the Garner words of a three-prime result go to the row's state lines
-            uint4* __restrict__ A4 = reinterpret_cast<uint4*>(st + (size_t)(2 * r) * N);
-            uint4* __restrict__ B4 = reinterpret_cast<uint4*>(st + (size_t)(2 * r + 1) * N);
-#pragma unroll
-            for (int g = 0; g < E / 4; ++g) {
-              uint32_t va[4], vb[4];
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                const uint32_t d0 = crt_fold0(acc0[4 * g + i], npc, T.pc, T.crt);
-                const uint32_t d1 = crt_digit1(acc1[4 * g + i], d0, npc, T.pc, T.crt);
-                va[i] = crt_value01_modq(d0, d1, T.crt);
-                vb[i] = crt_value01_modp2(d0, d1, T.pc, T.crt);
-              }
-              A4[g * 64 + li] = make_uint4(va[0], va[1], va[2], va[3]);
-              B4[g * 64 + li] = make_uint4(vb[0], vb[1], vb[2], vb[3]);
-            }
-          }
-        }
-        if (mode == SHORT_TWO) continue;
+        for (int g = 0; g < E / 4; ++g) P4[g * 64 + ln] = make_uint4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
       }
-
-      // ---- single pass under one prime (modes ONE, SPLIT; third prime of THREE): the transforms wait in P and in the
-      // scratch line while the rows' sums are formed and transformed back one after the other
-      const int pp = mode == SHORT_THREE ? 2 : 0;
-      const PrimeConsts pc = T.pc[pp];
-      const uint32_t* __restrict__ twf = tw_all + (size_t)(2 * pp) * kTableLen;
+    }
+    // ---- rows and their jobs: one inverse transform per key image (two in split mode)
+    const int njobs = one ? 1 : 2;
 #pragma unroll 1
-      for (uint32_t op = 2 - nit; op < 2; ++op) {
-        RZK_STEP_PRIORITY();
-        int ln = lane;
-        RZK_OPAQUE(ln);
-        uint32_t x[E];
-        if (mode == SHORT_THREE) {   // the raw words are gone: re-read the low words
-          double d0 = 0, d1 = 0;
-          uint64_t sq = 0;
-          bool f2 = false;
-          load_lift<LOGN>(x, op ? src1 : src0, ln, pc, false, d0, d1, false, sq, qhalf, f2);
-        } else {
+    for (uint32_t r = 0; r < (pair ? 2u : 1u); ++r) {
+      uint32_t keep[E];   // low half's integers (int32 bits)
+#pragma unroll 1
+      for (int j = 0; j < njobs; ++j) {
+        const int img = (one ? 0 : kImgLo) + j;
+        int li = lane;
+        RZK_OPAQUE(li);
+        uint32_t sacc[E];
 #pragma unroll
-          for (int e = 0; e < E; ++e) x[e] = lift(op ? v1[e] : v0[e], pc);
+        for (int c = 0; c < E; ++c) sacc[c] = 0;
+        if (r == 0 && nit == 2 && i0.keyA != kNoKey)
+          mac_key<LOGN, true>(sacc, nullptr, const_cast<const uint4*>(P4),
+                              reinterpret_cast<const uint4*>(key_ntt + ((size_t)i0.keyA * kKeyImages + img) * N), i0.signA < 0, li, pc);
+        const uint16_t kent = r ? i1.keyB : i1.keyA;
+        if (kent != kNoKey)
+          mac_key<LOGN, true>(sacc, nullptr, const_cast<const uint4*>(XL),
+                              reinterpret_cast<const uint4*>(key_ntt + ((size_t)kent * kKeyImages + img) * N),
+                              (r ? i1.signB : i1.signA) < 0, li, pc);
+        if (j == 1) {   // P is free now (row A's parked transform has just been used): the low half waits there
+#pragma unroll
+          for (int g = 0; g < E / 4; ++g) P4[g * 64 + li] = make_uint4(keep[4 * g], keep[4 * g + 1], keep[4 * g + 2], keep[4 * g + 3]);
         }
-        wave_fwd<LOGN>(x, ln, lds, twf, pc);
-        uint4* __restrict__ dst = op ? XL : P4;   // (generic store: LDS for the first operand, scratch line for the last)
-        if (op) {
+        wave_inv<LOGN>(sacc, li, lds, twf + kTableLen, pc);
+        if (j + 1 < njobs) {   // low half: residue mod p0 (lazy) -> the exact integer, |.| < 2^29
 #pragma unroll
-          for (int g = 0; g < E / 4; ++g) XL[g * 64 + ln] = make_uint4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
-        } else {
-#pragma unroll
-          for (int g = 0; g < E / 4; ++g) P4[g * 64 + ln] = make_uint4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
+          for (int e = 0; e < E; ++e) {
+            const uint32_t dd = csub(sacc[e], pc.p);
+            keep[e] = dd >= T.crt.half1 ? dd - pc.p : dd;
+          }
+          continue;
         }
-        (void)dst;
-      }
-      const int nimg = mode == SHORT_SPLIT ? 2 : 1;
-      const int img0 = mode == SHORT_SPLIT ? kImgLo : pp;
-#pragma unroll 1
-      for (uint32_t r = 0; r < (pair ? 2u : 1u); ++r) {
-        uint32_t u[E];   // SPLIT: the low half's integers first (int32 bits); in the end the row's value mod q
-#pragma unroll 1
-        for (int k = 0; k < nimg; ++k) {
-          RZK_STEP_PRIORITY();
-          const int img = img0 + k;
-          int li = lane;
-          RZK_OPAQUE(li);
-          uint32_t sacc[E];
+        if (one) {
 #pragma unroll
-          for (int c = 0; c < E; ++c) sacc[c] = 0;
-          if (r == 0 && nit == 2 && i0.keyA != kNoKey)
-            mac_key<LOGN, true>(sacc, nullptr, const_cast<const uint4*>(P4),
-                                reinterpret_cast<const uint4*>(key_ntt + ((size_t)i0.keyA * kKeyImages + img) * N), i0.signA < 0, li, pc);
-          const uint16_t kent = r ? i1.keyB : i1.keyA;
-          if (kent != kNoKey)
-            mac_key<LOGN, true>(sacc, nullptr, const_cast<const uint4*>(XL),
-                                reinterpret_cast<const uint4*>(key_ntt + ((size_t)kent * kKeyImages + img) * N),
-                                (r ? i1.signB : i1.signA) < 0, li, pc);
-          if (mode == SHORT_SPLIT && k == 1) {   // P is free now (row A's parked transform has been used): the low half's
-#pragma unroll                                    // integers wait there during the transform
-            for (int g = 0; g < E / 4; ++g) P4[g * 64 + li] = make_uint4(u[4 * g], u[4 * g + 1], u[4 * g + 2], u[4 * g + 3]);
-          }
-          uint4 sa[E / 4], sb[E / 4];
-          if (mode == SHORT_THREE) {   // Garner words of the row, requested before the transform
-            const uint4* __restrict__ A4 = reinterpret_cast<const uint4*>(st + (size_t)(2 * r) * N);
-            const uint4* __restrict__ B4 = reinterpret_cast<const uint4*>(st + (size_t)(2 * r + 1) * N);
+          for (int e = 0; e < E; ++e) sacc[e] = crt_finish_zq(crt_fold0(sacc[e], 1, T.pc, T.crt), 1, T.crt);
+        } else {   // value = lo + 2^16 hi (mod q) in 32-bit arithmetic: hi * 2^16 by one Montgomery step with 2^48 mod q
 #pragma unroll
-            for (int g = 0; g < E / 4; ++g) sa[g] = A4[g * 64 + li], sb[g] = B4[g * 64 + li];
-          }
-          wave_inv<LOGN>(sacc, li, lds, twf + kTableLen, pc);
-          if (mode == SHORT_ONE) {
+          for (int g = 0; g < E / 4; ++g) {
+            const uint4 lv = P4[g * 64 + li];
+            const uint32_t ls[4] = {lv.x, lv.y, lv.z, lv.w};
 #pragma unroll
-            for (int e = 0; e < E; ++e) u[e] = crt_finish_zq(crt_fold0(sacc[e], 1, T.pc, T.crt), 1, T.crt);
-          } else if (mode == SHORT_THREE) {
-#pragma unroll
-            for (int g = 0; g < E / 4; ++g) {
-              uint32_t a[4] = {sa[g].x, sa[g].y, sa[g].z, sa[g].w};
-              const uint32_t bb[4] = {sb[g].x, sb[g].y, sb[g].z, sb[g].w};
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                crt_fold2(sacc[4 * g + i], T.pc, T.crt, a[i], bb[i]);
-                u[4 * g + i] = crt_finish_zq(a[i], 3, T.crt);
-              }
-            }
-          } else if (k == 0) {   // SPLIT, low half: residue mod p0 (lazy, [0,2p0)) -> the exact integer, |.| < 2^29
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-              const uint32_t dd = csub(sacc[e], pc.p);
-              u[e] = dd >= T.crt.half1 ? dd - pc.p : dd;   // (int32 bits)
-            }
-          } else {               // SPLIT, high half: value = lo + 2^16 hi (mod q), hi * 2^16 by one Montgomery step
-#pragma unroll
-            for (int g = 0; g < E / 4; ++g) {
-              const uint4 lv = P4[g * 64 + li];
-              const uint32_t ls[4] = {lv.x, lv.y, lv.z, lv.w};
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                const uint32_t dd = csub(sacc[4 * g + i], pc.p);
-                const int32_t rr = (int32_t)(dd >= T.crt.half1 ? dd - pc.p : dd);
-                const uint32_t hi_q = montq_u(zq_from_centered(rr, T.crt.q), T.crt.r48q, T.crt);
-                u[4 * g + i] = addq(hi_q, zq_from_centered((int32_t)ls[i], T.crt.q), T.crt.q);
-              }
+            for (int i = 0; i < 4; ++i) {
+              const uint32_t dd = csub(sacc[4 * g + i], pc.p);
+              const int32_t rr = (int32_t)(dd >= T.crt.half1 ? dd - pc.p : dd);
+              const uint32_t hi_q = montq_u(zq_from_centered(rr, T.crt.q), T.crt.r48q, T.crt);
+              sacc[4 * g + i] = addq(hi_q, zq_from_centered((int32_t)ls[i], T.crt.q), T.crt.q);
             }
           }
         }
-        finish_row<LOGN>(u, prog, table_load(&prog->rows[r ? un.rowB : un.rowA]), ops, b, bo, lane, T, flags,
-                         (has_shift && r == 0) ? st_sh : nullptr);
+        finish_row<LOGN, 8>(sacc, prog, table_load(&prog->rows[r ? un.rowB : un.rowA]), ops, b, bo, lane, T, flags, nullptr);
       }
     }
   }
-#undef RZK_STEP_PRIORITY
 }
 
 // =============================================================================================
@@ -2520,7 +2318,8 @@ size_t row_scratch_words(int logn, int num_cus) { return (size_t)num_cus * 8 * 4
 template <int LOGN, bool HAS_VEC, bool HAS_SHIFT>
 static int launch_units_t(const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, const Operands& ops,
                           const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T, const uint32_t* d_tw,
-                          uint32_t* d_scratch, uint8_t* d_flags, uint32_t ntasks, uint32_t upt, uint32_t tpe, uint32_t wpt) {
+                          uint32_t* d_scratch, uint8_t* d_flags, uint32_t ntasks, uint32_t upt, uint32_t tpe, uint32_t wpt,
+                          const uint8_t* d_done) {
   using G = Geo<LOGN>;
   constexpr int WPB = UnitCfg<LOGN>::WPB;
   // per wave: transposition slab + P; then the workgroup's fairness table
@@ -2534,61 +2333,54 @@ static int launch_units_t(const LaunchCfg& cfg, const Program* d_prog, const Wav
   // at N = 512 — all resident, every wave walks its tasks with a grid stride.
   const unsigned grid = WPB == 16 ? grid_for(ntasks, cfg.num_cus, 16, LOGN <= 9 ? 2 : 1) : grid_for(ntasks, cfg.num_cus, 4, 8);
   hipLaunchKernelGGL((unit_kernel<LOGN, HAS_VEC, HAS_SHIFT>), dim3(grid), dim3(64 * WPB), lds, (hipStream_t)cfg.stream, d_prog,
-                     d_wp, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks, upt, tpe, wpt);
+                     d_wp, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks, upt, tpe, wpt, d_done);
   RZK_LAUNCH_CHECK();
   return 0;
 }
 
-template <int LOGN, bool HAS_SHIFT>
-static int launch_short_t(const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, const Operands& ops,
+template <int LOGN>
+static int launch_split_t(const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, const Operands& ops,
                           const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T, const uint32_t* d_tw,
-                          uint32_t* d_scratch, uint8_t* d_flags, uint32_t ntasks, uint32_t upt, uint32_t tpe, uint32_t wpt,
-                          uint32_t allow_split) {
+                          uint32_t* d_scratch, uint8_t* d_flags, uint8_t* d_done, uint32_t ntasks) {
   using G = Geo<LOGN>;
   const size_t lds = 4 * (size_t)(G::LDS_WORDS + G::N) * sizeof(uint32_t);   // per wave: transposition slab + P
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&short_kernel<LOGN, HAS_SHIFT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&split_kernel<LOGN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   const unsigned grid = grid_for(ntasks, cfg.num_cus, 4, 8);   // <= num_cus * 8 blocks (scratch sizing)
-  hipLaunchKernelGGL((short_kernel<LOGN, HAS_SHIFT>), dim3(grid), dim3(256), lds, (hipStream_t)cfg.stream, d_prog, d_wp, ops,
-                     d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks, upt, tpe, wpt, allow_split);
+  hipLaunchKernelGGL((split_kernel<LOGN>), dim3(grid), dim3(256), lds, (hipStream_t)cfg.stream, d_prog, d_wp, ops, d_key_ntt,
+                     d_key_inf, T, d_tw, d_scratch, d_flags, d_done, ntasks);
   RZK_LAUNCH_CHECK();
   return 0;
 }
 
-int launch_short(int logn, const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, uint32_t nunits,
-                 uint32_t units_per_task, uint32_t work_per_entry, bool has_shift, bool allow_split, const Operands& ops,
-                 const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T, const uint32_t* d_tw,
-                 uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch) {
-  if (batch == 0 || nunits == 0) return 0;
-  if (units_per_task == 0) units_per_task = 1;
-  const uint32_t tpe = (nunits + units_per_task - 1) / units_per_task;
-  if (batch * tpe >= (1ull << 32)) return -2;
-  const uint32_t ntasks = (uint32_t)(batch * tpe);
-  const uint32_t wpt = (work_per_entry + tpe - 1) / tpe;
-#define RZK_SHORT_ARGS cfg, d_prog, d_wp, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks, units_per_task, tpe, wpt, allow_split ? 1u : 0u
+int launch_split(int logn, const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, uint32_t nsplit,
+                 const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T,
+                 const uint32_t* d_tw, uint32_t* d_scratch, uint8_t* d_flags, uint8_t* d_done, uint64_t batch) {
+  if (batch == 0 || nsplit == 0) return 0;
+  if (batch * nsplit >= (1ull << 32)) return -2;
+  const uint32_t ntasks = (uint32_t)(batch * nsplit);
   switch (logn) {
-    case 9: return has_shift ? launch_short_t<9, true>(RZK_SHORT_ARGS) : launch_short_t<9, false>(RZK_SHORT_ARGS);
-    case 10: return has_shift ? launch_short_t<10, true>(RZK_SHORT_ARGS) : launch_short_t<10, false>(RZK_SHORT_ARGS);
-    case 11: return has_shift ? -1 : launch_short_t<11, false>(RZK_SHORT_ARGS);
+    case 9: return launch_split_t<9>(cfg, d_prog, d_wp, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, d_done, ntasks);
+    case 10: return launch_split_t<10>(cfg, d_prog, d_wp, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, d_done, ntasks);
+    case 11: return launch_split_t<11>(cfg, d_prog, d_wp, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, d_done, ntasks);
   }
-#undef RZK_SHORT_ARGS
   return -1;
 }
 
 int launch_units(int logn, const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, uint32_t nunits,
                  uint32_t units_per_task, uint32_t work_per_entry, bool has_vec, bool has_shift, const Operands& ops,
                  const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T, const uint32_t* d_tw,
-                 uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch) {
+                 uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch, const uint8_t* d_done) {
   if (batch == 0 || nunits == 0) return 0;
   if (units_per_task == 0) units_per_task = 1;
   const uint32_t tpe = (nunits + units_per_task - 1) / units_per_task;   // tasks per batch entry
   if (batch * tpe >= (1ull << 32)) return -2;   // task index is 32-bit
   const uint32_t ntasks = (uint32_t)(batch * tpe);
   const uint32_t wpt = (work_per_entry + tpe - 1) / tpe;   // transforms per task (estimate, for the progress priorities)
-#define RZK_UNIT_ARGS cfg, d_prog, d_wp, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks, units_per_task, tpe, wpt
+#define RZK_UNIT_ARGS cfg, d_prog, d_wp, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks, units_per_task, tpe, wpt, d_done
 #define RZK_UNIT_CASE(L)                                                                                            \
   case L:                                                                                                           \
     if (has_shift)                                                                                                  \

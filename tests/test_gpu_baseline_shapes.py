@@ -224,6 +224,40 @@ def test_forced_kernel_paths_vs_oracle(torch_mod, cfg):
     check_sum_cycle(torch_mod, ctx, A, 2, V, 602 + n, device_too=False)
 
 
+# ---- split_kernel (RZK_SPLIT=1): one prime per 16-bit key half for operands of small 1-norm -----------------------
+@pytest.mark.parametrize("N", [512, 1024, 2048])
+def test_split_kernel_vs_oracle(torch_mod, N):
+    """The per-proof decision of split_kernel: taken when 2^15 * (|r_1|_1 + |r_2|_1) fits prime 0, refused (and the
+    unit left to unit_kernel) one step beyond; a sparse operand that one prime covers outright; ternary r as the
+    commitments use it.  commit.rs:109-125 (oracle: O.commit)."""
+    n, k, l = 1, 3, 1
+    ctx = make_ctx(N, n, k, l, env={"RZK_SPLIT": 1})
+    P = P_of(ctx)
+    rng = np.random.default_rng(700 + N)
+    A = synth.key(rng, N, n, k, l)
+    ctx.load_key(A)
+    B = 6
+    x = synth.uniform(rng, (B, l, N))
+    r = np.zeros((B, k, N), dtype=np.int64)
+    r[0] = synth.small(rng, (k, N))                       # ternary: split
+    r[1, 1, 0], r[1, 2, 3] = 16000, -383                  # 1-norm 16383 over the two product operands: split
+    r[1, 0] = synth.small(rng, (N,))
+    r[2, 1, :N] = 8
+    r[2, 2, :N] = 8                                       # 1-norm 16 N: 8192 / 16384 / 32768 -> split, split, refused
+    r[3, 1, 0], r[3, 1, 1] = 16383, 1                     # 1-norm 16384: refused at every N (general path)
+    r[4, 2, 5] = -1                                       # a single -1: tiny 1-norm
+    r[5] = synth.uniform(rng, (k, N))                     # full range: refused
+    y = synth.gauss(rng, (B, k, N), P.sigma)
+    cm, okc = ctx.commit(x, r)
+    c, t, ok = ctx.open_commit(x, r, y)
+    for b in range(B):
+        c_ref, t_ref, ok_ref = O.open_commit(P, A, x[b], r[b], y[b])
+        assert np.array_equal(c[b], c_ref) and np.array_equal(t[b], t_ref) and bool(ok[b]) == ok_ref, b
+        assert np.array_equal(cm[b], c_ref) and bool(okc[b]) == ok_ref, b
+    # Commitment::verify (commit.rs:199-209) runs its rows through the same units
+    assert ctx.commitment_verify(c, x, r).tolist() == [int(bool(v)) for v in ok]
+
+
 # ---- non-canonical inputs ------------------------------------------------------------------------------------------
 def _open_proof(ctx, B, seed):
     P = P_of(ctx)

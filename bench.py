@@ -309,8 +309,24 @@ def main():
     # RZK_BENCH_PROF=0 times the loop without any event and profiles in a separate pass.
     prof_live = rank == 0 and os.environ.get("RZK_BENCH_PROF", "1") != "0"
     prof_every = 8
-    for _ in range(ramp + args.warmup):
-        step()
+    # the untimed steps also size the library's event pool (hipEventCreate is slow): as many profiled steps as the
+    # timed region will hold
+    nprof_steps = (args.steps + prof_every - 1) // prof_every if prof_live else 0
+    for i in range(max(ramp + args.warmup, nprof_steps, 1)):
+        if i < nprof_steps:
+            ctx.prof_enable(True)
+            step()
+            ctx.prof_enable(False)
+        elif i == 0 or i + 1 == ramp + args.warmup:
+            # everything the last timed step does, so that no first use (torch's reduction kernels, .item()) falls
+            # into the timed region
+            w_ok, w_acc = step(count=True)
+            assert int(w_ok.item()) >= 0 and int(w_acc.item()) >= 0
+        else:
+            step()
+    if nprof_steps:
+        w_ok, w_acc = step(count=True)
+        assert int(w_ok.item()) >= 0 and int(w_acc.item()) >= 0
     barrier()
     marks = []   # (launch count before the chunk, after commit, after response, after verify)
     if prof_live:

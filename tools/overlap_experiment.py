@@ -35,8 +35,11 @@ def run(S):
 
     def step():
         accs = []
-        for ph in range(3):
+        for slot in range(3):
             for i in range(S):
+                # staggered order: odd sub-batches run response before commit (the two are independent), so that an
+                # HBM-bound kernel and a VALU-bound one are in flight together from the first launch on
+                ph = slot if not (STAGGER and i % 2 and slot < 2) else 1 - slot
                 with torch.cuda.stream(streams[i]):
                     p = parts[i]
                     if ph == 0:
@@ -60,5 +63,9 @@ def run(S):
     print(f"streams={S}: {dt * 1e6:8.1f} us per {B}-proof cycle  {B / dt / 1e6:7.3f} M proofs/s  accepted {ok}")
 
 
-for S in [int(a) for a in sys.argv[1:]] or [1, 2, 3, 4]:
-    run(S)
+STAGGER = False
+args = [a for a in sys.argv[1:] if a != "--stagger"]
+for STAGGER in ([False, True] if "--stagger" in sys.argv else [False]):
+    print("stagger", STAGGER)
+    for S in [int(a) for a in args] or [1, 2, 3, 4]:
+        run(S)

@@ -98,6 +98,7 @@ struct rzk_ctx {
   uint32_t block_min_logn = 11;        // row blocks from this ring degree on (below it row groups do the sharing)
   bool use_groups = true;
   uint32_t units_per_task = 0;         // 0 = automatic (RZK_UPT overrides, tuning)
+  bool vec_rows = true;                // programs with vector x vector products: row_kernel (RZK_VEC_ROWS=0: unit_kernel)
   bool use_split = false;              // split_kernel for key products with small-norm operands: measured slower than
                                        // unit_kernel's two-prime pairs; RZK_SPLIT=1 turns it on
   bool use_pairs = true;               // unit_kernel: pair rows that share their last operand (RZK_PAIRS=0 turns it off, tuning)
@@ -855,6 +856,10 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
     uint32_t upt = batch >= (uint64_t)c->num_cus * 16 ? dp.nunits : 1;
     if (c->units_per_task) upt = c->units_per_task;   // RZK_UPT (tuning)
     uint8_t* d_done = nullptr;
+    if (dp.has_vec && c->vec_rows) {
+      lrc = launch_rows((int)c->logn, cfg_of(c), dp.d, dp.nrows, dp.has_shift, ops, c->d_key_ntt, c->d_key_inf, c->dT, c->d_tw,
+                        c->d_row_scratch, flags, batch);
+    } else {
     if (dp.nsplit) {   // small-norm operands first (split_kernel marks what it finished), everything else after
       int rc2 = arena_reserve(c, c->ws_done, (size_t)batch * dp.nunits);
       if (rc2 != RZK_OK) return rc2;
@@ -865,6 +870,7 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
     if (lrc == 0)
       lrc = launch_units((int)c->logn, cfg_of(c), dp.d, dp.d_wp, dp.nunits, upt, 2 * dp.work, dp.has_vec, dp.has_shift, ops,
                          c->d_key_ntt, c->d_key_inf, c->dT, c->d_tw, c->d_row_scratch, flags, batch, d_done);
+    }
   }
   if (lrc == -2) return fail(c, RZK_E_UNSUPPORTED, "batch * rows must stay below 2^32");
   if (lrc != 0) {
@@ -1039,6 +1045,7 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
   if (const char* e = std::getenv("RZK_PAIRS")) c->use_pairs = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_UPT")) c->units_per_task = (uint32_t)std::atoi(e);
   if (const char* e = std::getenv("RZK_SPLIT")) c->use_split = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RZK_VEC_ROWS")) c->vec_rows = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_BLOCK_MIN_LOGN")) c->block_min_logn = (uint32_t)std::atoi(e);   // 12 = never
 
   // twiddle tables: 3 primes x {fwd, inv} x kTableLen

@@ -186,6 +186,10 @@ struct LaunchCfg {
 
 // units_per_task: how many consecutive units of one batch entry a wavefront evaluates back to back (all of them =
 // one wavefront per proof: equal-cost tasks, no tail)
+// row_kernel: one wavefront per (batch entry, row); programs with vector x vector products
+int launch_rows(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows, bool has_shift, const Operands& ops,
+                const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* d_T, const uint32_t* d_tw,
+                uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch);
 // split_kernel over the program's split candidates; done[b * nunits + unit] = 1 for the units it finished
 int launch_split(int logn, const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, uint32_t nsplit,
                  const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* d_T,

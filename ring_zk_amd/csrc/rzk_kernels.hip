@@ -1108,6 +1108,85 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
 }
 
 // =============================================================================================
+// row_kernel: one wavefront per output row, for programs with vector x vector products (x_i (.) g_i sums, products
+// with the per-proof scalars g and f: linear.rs:94,124-129, sum.rs:107-115,154-160,301-319, commit.rs:199-209).
+// Such a term needs two forward transforms whose results must both be in registers for the multiplication, so the
+// unit kernel's register discipline (nothing live while an operand is transformed) does not apply; what pays here is
+// the running sum staying in registers across the terms and the Garner word A staying in LDS (measured against
+// unit_kernel's parked sums and global state lines: 1.36 vs 1.85 ms per launch for the Sum rows at (4,9,4), V = 8).
+// Primes one after the other; the first pass measures the operands (prime count, canonical test, norm marks).
+// =============================================================================================
+template <int LOGN, bool HAS_SHIFT>
+__global__ void __launch_bounds__(256, (LOGN <= 10 ? 4 : 1))   // N <= 1024: hold the 4 waves per SIMD the LDS allows
+row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t* __restrict__ key_ntt,
+           const double* __restrict__ key_inf, const DevTables* __restrict__ Tp, const uint32_t* __restrict__ tw_all,
+           uint32_t* __restrict__ scratch, uint8_t* __restrict__ flags, const uint32_t ntasks) {
+  using G = Geo<LOGN>;
+  constexpr int E = G::E;
+  constexpr int N = G::N;
+  constexpr bool OPQ = true;   // opaque lane ids: no hoisted address registers
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  // per wave: transposition slab, then Garner word A (one per coefficient); together they also hold the 2N-word
+  // image of a rotation term, which is finished before the transforms start
+  uint32_t* lds = smem + wave * (G::LDS_WORDS + N);
+  uint32_t* st_lds = lds + G::LDS_WORDS;
+  uint32_t* st = scratch + ((size_t)blockIdx.x * 4 + wave) * (size_t)(kScratchLines * N + 16);
+  uint32_t* st_glb = st;            // Garner word B, only touched when a row needs the third prime
+  uint32_t* st_sh = st + 4 * N;     // sum of the row's rotation terms mod q
+  const DevTables& T = *Tp;
+  const uint32_t qhalf = T.crt.qhalf;
+  const uint32_t nrows = prog->nrows;
+
+  for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
+    const uint32_t b = task / nrows;
+    const uint32_t rowi = task - b * nrows;
+    const uint32_t bo = ops.group > 1 ? b / ops.group : b;
+    const Row row = table_load(&prog->rows[rowi]);
+    const bool has_shift = HAS_SHIFT && row.nshift > 0;
+    if (has_shift) {
+      bool fault = false;
+#pragma unroll 1
+      for (uint32_t t = 0; t < row.nshift; ++t) {
+        const Term tm = table_load(&prog->terms[row.term0 + row.nterms + t]);
+        const int64_t* __restrict__ pa = operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N);
+        int32_t a[E];
+        uint32_t abad = 0, amx = 0;
+#pragma unroll
+        for (int e = 0; e < E; ++e) a[e] = canon_lo_mx(pa[G::j_p1(lane, e)], qhalf, abad, amx);
+        fault = fault || canon_fail(abad, amx, qhalf);
+        shift_product<LOGN, false, true>(st_sh, t == 0, tm.sign < 0, a, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane,
+                                         reinterpret_cast<int32_t*>(lds), T, fault);
+      }
+      if (fault) input_fault(ops, flags, bo, lane);
+      wave_sync();   // the image is dead: the slab and the state words may be overwritten
+    }
+    const bool has_terms = row.nterms > 0;
+    int np = kMaxPrimes;
+    if (has_terms) {
+      double bound = 0.0;
+#pragma unroll 1
+      for (int pi = 0; pi < np; ++pi) {
+        const PrimeConsts pc = T.pc[pi];
+        const uint32_t* __restrict__ twf = tw_all + (size_t)(2 * pi) * kTableLen;
+        const bool first = pi == 0;
+        uint32_t acc[E];
+#pragma unroll
+        for (int c = 0; c < E; ++c) acc[c] = 0;
+#pragma unroll 1
+        for (uint32_t t = 0; t < row.nterms; ++t)
+          term_direct<LOGN, true, OPQ>(acc, table_load(&prog->terms[row.term0 + t]), ops, b, bo, lane, lds, twf, pc, pi, key_ntt,
+                                       key_inf, first, bound, flags, qhalf);
+        if (first) np = primes_for(bound, T);
+        inverse_and_fold<LOGN, OPQ>(pi, np, acc, lane, lds, twf + kTableLen, pc, st_lds, st_glb, T);
+      }
+    }
+    row_epilogue<LOGN>(prog, row, ops, b, bo, lane, has_terms, np, st_lds, T, flags, has_shift ? st_sh : nullptr);
+  }
+}
+
+// =============================================================================================
 // split_kernel: key products whose operands have a SMALL 1-norm — the ternary randomness r of every commitment
 // (commit.rs:98-107: c = [a1;a2].r + [0;x] is a third of all transforms of an Open cycle).  With the key entries
 // available as two 16-bit halves under prime 0 (rzk_core.h, kKeyImages), K (*) v fits ONE prime per half whenever
@@ -2367,6 +2446,40 @@ int launch_split(int logn, const LaunchCfg& cfg, const Program* d_prog, const Wa
     case 10: return launch_split_t<10>(cfg, d_prog, d_wp, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, d_done, ntasks);
     case 11: return launch_split_t<11>(cfg, d_prog, d_wp, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, d_done, ntasks);
   }
+  return -1;
+}
+
+template <int LOGN, bool HAS_SHIFT>
+static int launch_rows_t(const LaunchCfg& cfg, const Program* d_prog, const Operands& ops, const uint32_t* d_key_ntt,
+                         const double* d_key_inf, const DevTables* T, const uint32_t* d_tw, uint32_t* d_scratch,
+                         uint8_t* d_flags, uint32_t ntasks) {
+  using G = Geo<LOGN>;
+  const size_t lds = 4 * (size_t)(G::LDS_WORDS + G::N) * sizeof(uint32_t);   // per wave: transposition slab + state word A
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&row_kernel<LOGN, HAS_SHIFT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const unsigned grid = grid_for(ntasks, cfg.num_cus, 4, 8);   // <= num_cus * 8 blocks (scratch sizing)
+  hipLaunchKernelGGL((row_kernel<LOGN, HAS_SHIFT>), dim3(grid), dim3(256), lds, (hipStream_t)cfg.stream, d_prog, ops,
+                     d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_rows(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows, bool has_shift, const Operands& ops,
+                const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T, const uint32_t* d_tw,
+                uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch) {
+  if (batch == 0 || nrows == 0) return 0;
+  if (batch * nrows >= (1ull << 32)) return -2;
+  const uint32_t ntasks = (uint32_t)(batch * nrows);
+#define RZK_ROWS_ARGS cfg, d_prog, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks
+  switch (logn) {
+    case 9: return has_shift ? launch_rows_t<9, true>(RZK_ROWS_ARGS) : launch_rows_t<9, false>(RZK_ROWS_ARGS);
+    case 10: return has_shift ? launch_rows_t<10, true>(RZK_ROWS_ARGS) : launch_rows_t<10, false>(RZK_ROWS_ARGS);
+    case 11: return has_shift ? launch_rows_t<11, true>(RZK_ROWS_ARGS) : launch_rows_t<11, false>(RZK_ROWS_ARGS);
+  }
+#undef RZK_ROWS_ARGS
   return -1;
 }
 

@@ -109,6 +109,31 @@ def min_transform_units(workload, n, k, l, V, rot):
 
 
 # ---- CPU baseline ---------------------------------------------------------------------------------------------------
+def cpu_ntt(N, p, psi, seconds=2.0):
+    """The same transform (Cooley-Tukey, table of psi powers in bit-reversed order, one 30-bit prime) on the host cores
+    (oracle/rzk_oracle.c, rzko_ntt_forward_batch): BASELINE.md §3.2's "same-algorithm CPU" figure next to the kernel's."""
+    import numpy as np
+
+    from oracle import oracle as O
+
+    threads = O.hw_threads()
+    psi_n = psi   # primitive 2N-th root of unity mod p (rzk_ntt_psi)
+    assert O.powmod(psi_n, N, p) == p - 1
+    rng = np.random.default_rng(7)
+    cnt = 64 * threads
+    a = rng.integers(0, p, (cnt, N), dtype=np.uint32)
+    t0 = time.perf_counter()
+    O.ntt_forward_batch(a, p, psi_n, threads, inplace=True)
+    dt = time.perf_counter() - t0
+    cnt = int(max(cnt, min(cnt * seconds / max(dt, 1e-6), 1 << 20)))
+    a = rng.integers(0, p, (cnt, N), dtype=np.uint32)
+    t0 = time.perf_counter()
+    O.ntt_forward_batch(a, p, psi_n, threads, inplace=True)
+    dt = time.perf_counter() - t0
+    return {"value": cnt * 2 * N * 4 / dt / 1e9, "unit": "GB/s", "polys_per_s": cnt / dt, "cores": threads, "kind": "port",
+            "sample": f"{cnt} residue polynomials of {N} coefficients in place, {dt:.2f} s"}
+
+
 def cpu_baseline(workload, N, n, k, l, V, seconds):
     """CPU restatement (oracle, schoolbook multiply, literal Mat::dot) timed on the host cores."""
     import numpy as np
@@ -443,6 +468,8 @@ def main():
             ntt_gbs = cnt * 2 * N * 4 / (ntt_us * 1e-6) / 1e9
             ntt = {"kernel": f"ntt_fwd_kernel<{N.bit_length() - 1}>", "polys": cnt, "avg_launch_us": ntt_us, "achieved": ntt_gbs,
                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ntt_gbs / HBM_PEAK_GBS}
+            if not args.no_cpu_baseline and world == 1:
+                ntt["cpu_same_algorithm"] = cpu_ntt(N, ctx.ntt_prime(0), ctx.ntt_psi(0))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -314,6 +314,18 @@ def ntt_forward(a, p: int, psi: int) -> np.ndarray:
     return a
 
 
+def ntt_forward_batch(a, p: int, psi: int, threads: int = 0, inplace: bool = False) -> np.ndarray:
+    """Table-driven forward transform of every row of a (count, N) on the host cores (bench.py: same-algorithm CPU leg)."""
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    if not inplace:
+        a = a.copy()
+    fn = lib().rzko_ntt_forward_batch
+    fn.restype = None
+    fn(C.c_uint32(p), C.c_uint32(psi), C.c_uint32(a.shape[-1]), C.c_uint64(a.size // a.shape[-1]),
+       a.ctypes.data_as(_U32P), C.c_int(threads))
+    return a
+
+
 def ntt_inverse(a, p: int, psi: int) -> np.ndarray:
     a = np.ascontiguousarray(a, dtype=np.uint32).copy()
     lib().rzko_ntt_inverse(C.c_uint32(p), C.c_uint32(psi), C.c_uint32(a.shape[-1]), a.ctypes.data_as(_U32P))

@@ -586,6 +586,39 @@ void rzko_ntt_inverse(uint32_t p, uint32_t psi, uint32_t N, uint32_t* a) {
   for (uint32_t j = 0; j < N; ++j) a[j] = (uint32_t)((uint64_t)a[j] * ninv % p);
 }
 
+/* Batched forward transform with a precomputed twiddle table (psi^{brv(i)}, i < N): the same Cooley-Tukey
+ * decimation-in-time schedule as rzko_ntt_forward and as the GPU's ntt_fwd_kernel, run over `count` residue
+ * polynomials on the host cores.  bench.py times it next to the GPU kernel ("same-algorithm CPU");
+ * tests check it against rzko_ntt_forward. */
+void rzko_ntt_forward_batch(uint32_t p, uint32_t psi, uint32_t N, uint64_t count, uint32_t* data, int threads) {
+  int lg = ilog2(N);
+  uint32_t* tw = (uint32_t*)malloc(sizeof(uint32_t) * N);
+  for (uint32_t i = 0; i < N; ++i) tw[i] = rzko_powmod(psi, bitrev(i, lg), p);
+#ifdef _OPENMP
+  if (threads <= 0) threads = omp_get_max_threads();
+#pragma omp parallel for num_threads(threads) schedule(static)
+#endif
+  for (uint64_t b = 0; b < count; ++b) {
+    uint32_t* a = data + b * N;
+    uint32_t t = N;
+    for (uint32_t m = 1; m < N; m <<= 1) {
+      t >>= 1;
+      for (uint32_t i = 0; i < m; ++i) {
+        const uint64_t W = tw[m + i];
+        const uint32_t j1 = 2 * i * t;
+        for (uint32_t j = j1; j < j1 + t; ++j) {
+          const uint32_t u = a[j];
+          const uint32_t v = (uint32_t)((uint64_t)a[j + t] * W % p);
+          const uint32_t s = u + v, d = u + p - v;   /* p < 2^30: no overflow */
+          a[j] = s >= p ? s - p : s;
+          a[j + t] = d >= p ? d - p : d;
+        }
+      }
+    }
+  }
+  free(tw);
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* batch driver for the timed CPU baseline                                                    */
 /* ------------------------------------------------------------------------------------------ */

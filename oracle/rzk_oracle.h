@@ -146,6 +146,7 @@ int rzko_sum_verify(const rzko_params* P, uint32_t V, const int64_t* A, const in
 /* In-place negacyclic forward NTT mod p: natural order in, bit-reversed order out (Cooley-Tukey,
  * merged psi twist).  psi = primitive 2N-th root of unity mod p.  Values in [0,p). */
 void rzko_ntt_forward(uint32_t p, uint32_t psi, uint32_t N, uint32_t* a);
+void rzko_ntt_forward_batch(uint32_t p, uint32_t psi, uint32_t N, uint64_t count, uint32_t* data, int threads);
 /* inverse of the above: bit-reversed in, natural out, scaled by N^-1 */
 void rzko_ntt_inverse(uint32_t p, uint32_t psi, uint32_t N, uint32_t* a);
 uint32_t rzko_powmod(uint32_t base, uint64_t e, uint32_t p);

@@ -191,3 +191,20 @@ def test_commitment_verify_with_scalar_f():
     big = rng.integers(-half, half + 1, (k, N))              # norm constraint on r comes first (commit.rs:183-185)
     cb, okb = O.commit(P, A, x, big)
     assert not okb and not O.commitment_verify(P, A, cb, x, big) and not O.commitment_verify(P, A, cb, x, big, one)
+
+
+def test_oracle_batched_ntt_matches_the_single_transform():
+    # the table-driven batch transform bench.py times on the host cores ("same-algorithm CPU") = rzko_ntt_forward per row
+    p = 1073668097
+    rng = np.random.default_rng(6)
+    for N in (512, 2048):
+        for gcand in range(2, 100):
+            psi = O.powmod(gcand, (p - 1) // (2 * N), p)
+            if O.powmod(psi, N, p) == p - 1:
+                break
+        a = rng.integers(0, p, (5, N), dtype=np.uint32)
+        a[0, :] = p - 1
+        got = O.ntt_forward_batch(a, p, psi, threads=2)
+        for i in range(a.shape[0]):
+            assert np.array_equal(got[i], O.ntt_forward(a[i], p, psi)), (N, i)
+

@@ -241,6 +241,9 @@ __device__ __forceinline__ void load_pairs(int32_t* v, const int64_t* __restrict
 #ifndef RZK_SHIFT_H
 #define RZK_SHIFT_H 8   // outputs of a lane accumulated per scan over the multiplier's non-zeros
 #endif
+#ifndef RZK_SHIFT_H_MEM
+#define RZK_SHIFT_H_MEM 16   // ... for the rotation terms inside the row kernels (sums go to the wave's scratch line)
+#endif
 // walk the non-zero coefficients of the multiplier (registers a[], lane-distributed in layout PAIR) and add
 // the rotations into IN outputs of every lane; `ext` already points at the first of them
 template <int LOGN, bool PAIR, int IN>
@@ -326,7 +329,8 @@ __device__ __forceinline__ void shift_product(uint32_t* res, bool fresh, bool mi
                                               const DevTables& T, bool& fault) {
   using S = ShiftGeo<LOGN, PAIR>;
   constexpr int E = S::E;
-  constexpr int H = RZK_SHIFT_H < E ? RZK_SHIFT_H : E;   // outputs per scan; chunk c covers registers c*H .. c*H+H-1
+  constexpr int HW = TO_MEM ? RZK_SHIFT_H_MEM : RZK_SHIFT_H;   // (the in-kernel rotation terms run with nothing else live)
+  constexpr int H = HW < E ? HW : E;   // outputs per scan; chunk c covers registers c*H .. c*H+H-1
   constexpr int NCH = E / H;
   const uint32_t q = T.crt.q, qhalf = T.crt.qhalf;
   // optimistic first fill with the whole values; it also measures v

@@ -207,20 +207,26 @@ __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict
 // =============================================================================================
 // Row-program kernels: the fused product / accumulate / reduce pipeline of every protocol phase.
 //
-// One wavefront evaluates one output row of one proof (rzk_dev.h).  Control flow is wave-uniform
-// and scalar (the wave index is read with readfirstlane).  Primes are processed one after the
-// other; each inverse transform is folded at once into the running Garner state (rzk_core.h,
-// crt_fold*), which lives in LDS (word A) and, for a third prime only, in a per-wave global
-// scratch line (word B), so no state occupies registers during the transforms.
+// A wavefront owns polynomial-sized pieces of one proof (rzk_dev.h).  Control flow is wave-uniform and scalar (the
+// wave index is read with readfirstlane).  Primes are processed one after the other; each inverse transform is folded
+// at once into the running Garner state (rzk_core.h, crt_fold*), so no state occupies registers during the transforms.
+// The operands' norms are measured while they are loaded for the first prime, which fixes how many primes (1..3) the
+// exact result needs; the same pass proves that every coefficient is canonical.  Which kernel runs a program is
+// decided once per (program, shape) in rzk_api.cpp:
 //
-//   row_kernel        transforms the operands of every term inside the wave; the operands' norms are
-//                     measured while they are loaded for the first prime, which fixes how many primes
-//                     (1..3) the exact result needs.  Best when rows share few operands ((n,k,l)=(1,3,1)).
-//   fwd_slots_kernel  + row_slots_kernel: when many rows of a proof use the same operands (key blocks
-//                     with n > 1, sums over V summands), every distinct operand ("slot") is transformed
-//                     ONCE per proof into a workspace in HBM (L2-resident per proof), and the rows only
-//                     multiply-accumulate the stored transforms; rows that need more primes than were
-//                     stored fall back to in-wave transforms for the missing primes, so results stay exact.
+//   unit_kernel       key-product programs (the default): one wavefront per proof walks the program's units — single
+//                     rows, or pairs of rows that share their last operand; sums parked in LDS, Garner words in
+//                     per-wave global scratch lines.
+//   row_kernel        programs with vector x vector products: one wavefront per row, sum in registers, Garner word A
+//                     in LDS.
+//   shift_row_kernel  rows whose products all have the sparse challenge as multiplier: rotations, no transform.
+//   row_group_kernel  (N <= 1024) / row_block_kernel (N = 2048): key blocks with n > 1, operands transformed once for
+//                     several rows.
+//   fwd_slots_kernel  + row_slots_kernel: when many rows of a proof use the same operands (sums over V summands at large
+//                     shapes), every distinct operand ("slot") is transformed ONCE per proof into a workspace in HBM,
+//                     and the rows only multiply-accumulate the stored transforms; rows that need more primes than
+//                     were stored fall back to in-wave transforms for the missing primes, so results stay exact.
+//   split_kernel      experiment (RZK_SPLIT=1): one prime per 16-bit key half for operands of small 1-norm.
 // =============================================================================================
 #ifndef RZK_ROW_MIN_WAVES
 #define RZK_ROW_MIN_WAVES 1   // minimum waves per SIMD the row kernels are compiled for (register budget)

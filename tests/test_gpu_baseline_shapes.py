@@ -214,6 +214,10 @@ def test_config5_shape_vs_oracle(torch_mod):
                                             "RZK_SHIFT": 0}),
     # groups of two rows only
     dict(N=1024, shape=(4, 9, 4), V=2, env={"RZK_GROUP_MAX": 2}),
+    # vector x vector programs through unit_kernel's HAS_VEC variants (the default sends them to row_kernel)
+    dict(N=1024, shape=(1, 3, 1), V=3, env={"RZK_VEC_ROWS": 0}),
+    dict(N=512, shape=(2, 5, 2), V=2, env={"RZK_VEC_ROWS": 0, "RZK_SLOT_SHARE_MIN": 0}),
+    dict(N=2048, shape=(1, 3, 1), V=2, env={"RZK_VEC_ROWS": 0}),
 ])
 def test_forced_kernel_paths_vs_oracle(torch_mod, cfg):
     N, (n, k, l), V = cfg["N"], cfg["shape"], cfg["V"]

@@ -1,0 +1,81 @@
+"""Randomised parity sweep (GPU): shapes, batch sizes, summand counts and tuning knobs drawn from a seeded generator,
+every phase of the three protocols compared with the oracle (oracle/rzk_oracle.c) through the C ABI.
+
+The fixed-shape tests pin the BASELINE configurations; this file walks the space between them — keys with k beyond
+n + l + 1 (several random columns in a2'), n = l in 1..3, ragged batch sizes (1, 2, 3, 5), V = 1, and the kernel choices
+the knobs switch — so that an indexing slip which happens to cancel at (1,3,1) or (4,9,4) still shows.
+Reference: src/commit.rs:33-60,109-125, src/prove/open.rs:80-174, linear.rs:82-250, sum.rs:99-320.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from ring_zk_amd import synth
+
+from test_gpu_baseline_shapes import P_of, check_key_products_and_open, check_sum_cycle, make_ctx, torch_mod  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+KNOBS = [
+    {},
+    {"RZK_ROW_GROUPS": 0},
+    {"RZK_SHIFT": 0},
+    {"RZK_PAIRS": 0},
+    {"RZK_VEC_ROWS": 0},
+    {"RZK_SPLIT": 1},
+    {"RZK_UPT": 1},
+    {"RZK_SLOT_SHARE_MIN": 0, "RZK_ROW_GROUPS": 0},
+    {"RZK_BLOCK_MIN_LOGN": 10},
+]
+
+
+def draw_case(seed):
+    rng = np.random.default_rng(9000 + seed)
+    N = int(rng.choice([512, 512, 1024, 1024, 2048]))
+    nl = int(rng.choice([1, 1, 2, 3]))
+    extra = int(rng.choice([1, 1, 2, 3]))            # random columns of a2'
+    k = 2 * nl + extra
+    if N == 2048 and nl == 3:                         # keep the schoolbook oracle in seconds
+        nl, k = 2, 4 + extra
+    B = int(rng.choice([1, 2, 3, 5]))
+    V = int(rng.choice([1, 2, 3, 5]))
+    if N == 2048:
+        B, V = min(B, 2), min(V, 3)
+    env = KNOBS[int(rng.integers(0, len(KNOBS)))]
+    return dict(N=N, n=nl, k=k, l=nl, B=B, V=V, env=env, seed=seed)
+
+
+def check_linear_cycle(ctx, A, B, seed):
+    P = P_of(ctx)
+    N, k, l = ctx.N, ctx.k, ctx.l
+    rng = np.random.default_rng(seed)
+    g = synth.uniform(rng, (B, N))
+    x = synth.uniform(rng, (B, l, N))
+    r, rp = synth.small(rng, (B, k, N)), synth.small(rng, (B, k, N))
+    y, yp = synth.gauss(rng, (B, k, N), P.sigma), synth.gauss(rng, (B, k, N), P.sigma)
+    d = synth.challenge(rng, (B,), N, P.kappa)
+    c, cp, t, tp, u, ok = ctx.linear_commit(g, x, r, rp, y, yp)
+    z, zp = ctx.linear_response(y, yp, r, rp, d)
+    zt = z.copy()
+    zt[B - 1, k - 1, N - 1] = O.center(int(zt[B - 1, k - 1, N - 1]) + 1)
+    acc, acct = ctx.linear_verify(z, zp, c, cp, g, t, tp, u, d), ctx.linear_verify(zt, zp, c, cp, g, t, tp, u, d)
+    for b in range(B):
+        ref = O.linear_commit(P, A, g[b], x[b], r[b], rp[b], y[b], yp[b])          # linear.rs:82-140
+        for got, want, name in zip((c, cp, t, tp, u), ref[:5], ("c", "cp", "t", "tp", "u")):
+            assert np.array_equal(got[b], want), (name, b)
+        assert int(ok[b]) == ref[5]
+        zr, zpr = O.linear_response(P, y[b], yp[b], r[b], rp[b], d[b])              # linear.rs:144-158
+        assert np.array_equal(z[b], zr) and np.array_equal(zp[b], zpr)
+        assert O.linear_verify(P, A, z[b], zp[b], c[b], cp[b], g[b], t[b], tp[b], u[b], d[b]) == 1   # linear.rs:213-250
+    assert acc.tolist() == [1] * B and acct.tolist() == [1] * (B - 1) + [0]
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_shape_all_protocols_vs_oracle(torch_mod, seed):
+    cs = draw_case(seed)
+    ctx = make_ctx(cs["N"], cs["n"], cs["k"], cs["l"], env=cs["env"])
+    A = synth.key(np.random.default_rng(9100 + seed), cs["N"], cs["n"], cs["k"], cs["l"])
+    ctx.load_key(A)
+    check_key_products_and_open(ctx, A, cs["B"], 9200 + seed)
+    check_linear_cycle(ctx, A, cs["B"], 9300 + seed)
+    check_sum_cycle(torch_mod, ctx, A, cs["B"], cs["V"], 9400 + seed, device_too=(seed % 3 == 0))

@@ -82,8 +82,10 @@ def run(S, graph, stagger=False):
     print(f"N={N} B={B} streams={S} graph={graph} stagger={stagger}: {dt * 1e6:8.1f} us per cycle  {B / dt / 1e6:7.3f} M proofs/s  accepted {ok}", flush=True)
 
 
-def run_fork(graph):
-    """One batch; commit and response (independent) on two streams, verify after both."""
+def run_fork(graph, prio=False):
+    """One batch; commit and response (independent) on two streams, verify after both.  prio: commit / verify on a
+    high-priority stream, response on a normal one, so that response workgroups only take the slots commit's retiring
+    waves leave."""
     ca, cb = Context(N, n, k, l, device=0), Context(N, n, k, l, device=0)
     gk = torch.Generator(device=dev)
     gk.manual_seed(1234)
@@ -96,8 +98,8 @@ def run_fork(graph):
     x = synth.t_uniform(g, (B, l, N), dev)
     r = synth.t_small(g, (B, k, N), dev)
     y = synth.t_gauss(g, (B, k, N), dev, ca.sigma)
-    side = torch.cuda.Stream()
-    main = torch.cuda.Stream()
+    side = torch.cuda.Stream(priority=0)
+    main = torch.cuda.Stream(priority=-1 if prio else 0)
 
     def step():
         cur = torch.cuda.current_stream()
@@ -126,11 +128,12 @@ def run_fork(graph):
             run_step()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
-    print(f"N={N} B={B} fork commit||response graph={graph}: {dt * 1e6:8.1f} us per cycle  {B / dt / 1e6:7.3f} M proofs/s  accepted {int(acc.sum())}", flush=True)
+    print(f"N={N} B={B} fork commit||response graph={graph} prio={prio}: {dt * 1e6:8.1f} us per cycle  {B / dt / 1e6:7.3f} M proofs/s  accepted {int(acc.sum())}", flush=True)
 
 
 run_fork(False)
-run_fork(True)
+run_fork(False, True)
+run_fork(True, True)
 for S in SS:
     run(S, False)
     run(S, True)

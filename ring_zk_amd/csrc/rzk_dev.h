@@ -148,7 +148,7 @@ struct SlotTable {
 // together.  One 8-wave workgroup evaluates a block of one proof prime by prime: the waves transform the
 // block's operands into LDS (each exactly once), meet at a barrier, then every wave evaluates rows from the
 // staged transforms.  For [a1;a2].r at (8,17,8) that is 9 transforms per prime and block instead of 72 + 8.
-constexpr int kBlockWaves = 8;     // (9, one per staged operand, measured slightly slower)
+constexpr int kBlockWaves = 8;     // (9 measured slightly slower in round 1; 10 — no idle wave in the operand phase — +0.7 % in round 2: noise)
 constexpr int kBlockMaxSlots = 9;    // staged operand transforms per block: 9 * 4N bytes of LDS (72 KiB at N = 2048)
 constexpr int kBlockMaxRows = 16;    // rows per block (two Garner state lines each in the workgroup's scratch)
 struct BlockDesc {

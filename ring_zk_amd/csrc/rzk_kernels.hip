@@ -1591,14 +1591,22 @@ row_group_kernel(const Program* __restrict__ prog, const Operands ops, const uin
               if (first) bound[g] += key_inf[tg.a_off] * l1;
               const uint4* __restrict__ kp =
                   reinterpret_cast<const uint4*>(key_ntt + ((size_t)tg.a_off * kKeyImages + pi) * N);
+              if (tg.sign >= 0) {   // (one wave-uniform branch per term, not a select per coefficient)
 #pragma unroll
-              for (int q4 = 0; q4 < E / 4; ++q4) {
-                const uint4 kv = kp[q4 * 64 + ln];
-                const uint32_t ks[4] = {kv.x, kv.y, kv.z, kv.w};
+                for (int q4 = 0; q4 < E / 4; ++q4) {
+                  const uint4 kv = kp[q4 * 64 + ln];
+                  const uint32_t ks[4] = {kv.x, kv.y, kv.z, kv.w};
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                  acc[g][4 * q4 + i] = tg.sign >= 0 ? mac_add(acc[g][4 * q4 + i], x[4 * q4 + i], ks[i], pc)
-                                                    : mac_sub(acc[g][4 * q4 + i], x[4 * q4 + i], ks[i], pc);
+                  for (int i = 0; i < 4; ++i) acc[g][4 * q4 + i] = mac_add(acc[g][4 * q4 + i], x[4 * q4 + i], ks[i], pc);
+                }
+              } else {
+#pragma unroll
+                for (int q4 = 0; q4 < E / 4; ++q4) {
+                  const uint4 kv = kp[q4 * 64 + ln];
+                  const uint32_t ks[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) acc[g][4 * q4 + i] = mac_sub(acc[g][4 * q4 + i], x[4 * q4 + i], ks[i], pc);
+                }
               }
             }
           }
@@ -1679,13 +1687,15 @@ row_block_kernel(const Program* __restrict__ prog, const BlockPlan* __restrict__
         uint64_t sumsq = 0;
         const bool chk = first && plan->slot_check[gs] && ops.norm_limit;
         bool fault = false;
-        load_lift<LOGN>(x, operand_ptr(ops, plan->slot_op[gs], plan->slot_off[gs], b, bo, N), lane, pc, first, l1, linf,
+        int ln = lane;
+        asm volatile("" : "+v"(ln));   // opaque lane ids: no lane-dependent addresses kept in registers across the steps
+        load_lift<LOGN>(x, operand_ptr(ops, plan->slot_op[gs], plan->slot_off[gs], b, bo, N), ln, pc, first, l1, linf,
                         chk, sumsq, T.crt.qhalf, fault);
         if (chk && sumsq >= ops.norm_limit && lane == 0) flags[bo] = 0;
         if (fault) input_fault(ops, flags, bo, lane);
         if (first && lane == 0) norm1[s] = l1;
-        wave_fwd<LOGN>(x, lane, lds, twf, pc);
-        uint32_t* dst = staged + s * N + lane;
+        wave_fwd<LOGN>(x, ln, lds, twf, pc);
+        uint32_t* dst = staged + s * N + ln;
 #pragma unroll
         for (int c = 0; c < E; ++c) dst[c * 64] = x[c];
       }
@@ -1714,21 +1724,30 @@ row_block_kernel(const Program* __restrict__ prog, const BlockPlan* __restrict__
 #pragma unroll 1
         for (uint32_t t = 0; t < row.nterms; ++t) {
           const Term tm = prog->terms[row.term0 + t];
-          const uint32_t* __restrict__ xs = staged + (size_t)plan->term_slot[row.term0 + t] * N + lane;
+          int lm = lane;
+          asm volatile("" : "+v"(lm));
+          const uint32_t* __restrict__ xs = staged + (size_t)plan->term_slot[row.term0 + t] * N + lm;
           const uint4* __restrict__ kp = reinterpret_cast<const uint4*>(key_ntt + ((size_t)tm.a_off * kKeyImages + pi) * N);
+          if (tm.sign >= 0) {   // (one wave-uniform branch per term, not a select per coefficient)
 #pragma unroll
-          for (int g = 0; g < E / 4; ++g) {
-            const uint4 kv = kp[g * 64 + lane];
-            const uint32_t ks[4] = {kv.x, kv.y, kv.z, kv.w};
+            for (int g = 0; g < E / 4; ++g) {
+              const uint4 kv = kp[g * 64 + lm];
+              const uint32_t ks[4] = {kv.x, kv.y, kv.z, kv.w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const uint32_t xv = xs[(4 * g + i) * 64];
-              acc[4 * g + i] = tm.sign >= 0 ? mac_add(acc[4 * g + i], xv, ks[i], pc) : mac_sub(acc[4 * g + i], xv, ks[i], pc);
+              for (int i = 0; i < 4; ++i) acc[4 * g + i] = mac_add(acc[4 * g + i], xs[(4 * g + i) * 64], ks[i], pc);
+            }
+          } else {
+#pragma unroll
+            for (int g = 0; g < E / 4; ++g) {
+              const uint4 kv = kp[g * 64 + lm];
+              const uint32_t ks[4] = {kv.x, kv.y, kv.z, kv.w};
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[4 * g + i] = mac_sub(acc[4 * g + i], xs[(4 * g + i) * 64], ks[i], pc);
             }
           }
         }
-        inverse_and_fold<LOGN>(pi, np, acc, lane, lds, twf + kTableLen, pc, st + (size_t)(2 * r) * N,
-                               st + (size_t)(2 * r + 1) * N, T);
+        inverse_and_fold<LOGN, true>(pi, np, acc, lane, lds, twf + kTableLen, pc, st + (size_t)(2 * r) * N,
+                                     st + (size_t)(2 * r + 1) * N, T);
       }
       __syncthreads();   // the staged transforms are overwritten by the next prime / next task
     }
@@ -1736,6 +1755,29 @@ row_block_kernel(const Program* __restrict__ prog, const BlockPlan* __restrict__
     for (uint32_t r = wave; r < bd.nrows; r += kBlockWaves) {
       const Row row = prog->rows[bd.row0 + r];
       row_epilogue<LOGN>(prog, row, ops, b, bo, lane, row.nterms > 0, np, st + (size_t)(2 * r) * N, T, flags);
+    }
+  }
+}
+
+// acc +/-= stored transform (*) (key entry | second stored transform), 16-byte accesses in the NTT-domain layout
+template <int LOGN, bool VEC, bool MINUS>
+__device__ __forceinline__ void slot_mac(uint32_t* acc, const uint4* __restrict__ xb, const uint4* __restrict__ other, int lane,
+                                         const PrimeConsts& pc) {
+  constexpr int E = Geo<LOGN>::E;
+#pragma unroll
+  for (int g = 0; g < E / 4; ++g) {
+    const uint4 xv = xb[g * 64 + lane];
+    const uint4 ov = other[g * 64 + lane];
+    uint32_t xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    const uint32_t os[4] = {ov.x, ov.y, ov.z, ov.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t w = os[i];
+      if (VEC) {   // x_a * x_b * N^-1: two Montgomery steps (the key already carries N^-1 * R)
+        xs[i] = mont_lazy(xs[i], os[i], pc.p, pc.npinv);
+        w = pc.ninv_r2;
+      }
+      acc[4 * g + i] = MINUS ? mac_sub(acc[4 * g + i], xs[i], w, pc) : mac_add(acc[4 * g + i], xs[i], w, pc);
     }
   }
 }
@@ -1879,21 +1921,14 @@ row_slots_kernel(const Program* __restrict__ prog, const SlotTable* __restrict__
                 vec ? reinterpret_cast<const uint4*>(
                           ws + (((size_t)b * nslots + slots->term_a[row.term0 + t]) * np_store + pi) * N)
                     : reinterpret_cast<const uint4*>(key_ntt + ((size_t)tm.a_off * kKeyImages + pi) * N);
-#pragma unroll
-            for (int g = 0; g < E / 4; ++g) {
-              const uint4 xv = xb[g * 64 + lane];
-              const uint4 ov = other[g * 64 + lane];
-              uint32_t xs[4] = {xv.x, xv.y, xv.z, xv.w};
-              const uint32_t os[4] = {ov.x, ov.y, ov.z, ov.w};
-#pragma unroll
-              for (int i = 0; i < 4; ++i) {
-                uint32_t w = os[i];
-                if (vec) {   // x_a * x_b * N^-1: two Montgomery steps (the key already carries N^-1 * R)
-                  xs[i] = mont_lazy(xs[i], os[i], pc.p, pc.npinv);
-                  w = pc.ninv_r2;
-                }
-                acc[4 * g + i] = tm.sign >= 0 ? mac_add(acc[4 * g + i], xs[i], w, pc) : mac_sub(acc[4 * g + i], xs[i], w, pc);
-              }
+            // four straight-line variants behind wave-uniform branches (a select per coefficient would evaluate both
+            // the add and the subtract form)
+            if (vec) {
+              if (tm.sign >= 0) slot_mac<LOGN, true, false>(acc, xb, other, lane, pc);
+              else slot_mac<LOGN, true, true>(acc, xb, other, lane, pc);
+            } else {
+              if (tm.sign >= 0) slot_mac<LOGN, false, false>(acc, xb, other, lane, pc);
+              else slot_mac<LOGN, false, true>(acc, xb, other, lane, pc);
             }
           }
         } else {

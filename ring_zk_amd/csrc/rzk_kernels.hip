@@ -665,6 +665,21 @@ template <int LOGN, bool to_regs, bool MINUS>
 __device__ __forceinline__ void mac_park_signed(uint32_t* x, const uint32_t* mul, uint4* P4, int lane, bool init,
                                                 const PrimeConsts& pc) {
   constexpr int E = Geo<LOGN>::E;
+  if (init && !MINUS) {   // first product of a sum: the lazy product IS the sum ([0,2p)), no add and no conditional subtract
+#pragma unroll
+    for (int g = 0; g < E / 4; ++g) {
+      uint32_t as[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) as[i] = mont_lazy(x[4 * g + i], mul[4 * g + i], pc.p, pc.npinv);
+      if (to_regs) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[4 * g + i] = as[i];
+      } else {
+        P4[g * 64 + lane] = make_uint4(as[0], as[1], as[2], as[3]);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int g = 0; g < E / 4; ++g) {
     uint4 a = make_uint4(0, 0, 0, 0);

@@ -35,6 +35,11 @@ for _ in range(300):
         o = ctx.polymul(a_, b_)
     elif what == "matvec1":
         o = ctx.matvec(0, y)
+    elif what == "open_verify":
+        if _ == 0:
+            c, t, ok = ctx.open_commit(x, r, y)
+            z = ctx.open_response(y, r, d)
+        acc = ctx.open_verify(z, t, c, d)
     else:
         c, t, ok = ctx.open_commit(x, r, y)
 torch.cuda.synchronize()

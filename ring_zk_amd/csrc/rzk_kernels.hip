@@ -913,7 +913,7 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
 #if RZK_STAMPS   // diagnostic build only (tools/wave_timeline.py): when each wavefront ran and where
   const uint64_t stamp0 = __builtin_amdgcn_s_memrealtime();
   const uint64_t cyc0 = __builtin_amdgcn_s_memtime();
-  uint64_t t_load = 0, t_fwd = 0, t_mac = 0, t_inv = 0, t_fin = 0;
+  uint64_t t_load = 0, t_fwd = 0, t_mac = 0, t_inv = 0, t_fin = 0, t_rot = 0;
 #endif
   const DevTables& T = *Tp;
   const uint32_t qhalf = T.crt.qhalf;
@@ -958,6 +958,7 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
         // challenge products first (rotations, image in slab + P); their sum mod q is built in the wave's scratch line
         // (every lane reads and writes only its own coefficients) and waits there for finish_row
         bool fault = false;
+        RZK_T0();
 #pragma unroll 1
         for (uint32_t t = 0; t < rowA.nshift; ++t) {
           const Term tm = table_load(&prog->terms[rowA.term0 + rowA.nterms + t]);
@@ -972,6 +973,7 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
         }
         if (fault) input_fault(ops, flags, bo, lane);
         wave_sync();   // the image is dead: slab and P may be overwritten
+        RZK_T1(t_rot);
       }
       int np = null_unit ? 1 : kMaxPrimes;
       const uint32_t nit = null_unit ? 1u : un_items;
@@ -1127,7 +1129,7 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
     o[4] = hwid, o[5] = xcc, o[6] = blockIdx.x, o[7] = wave;
     const uint64_t cyc1 = __builtin_amdgcn_s_memtime();
     o[8] = (uint32_t)(cyc1 - cyc0);   // shader-clock cycles of the wave's lifetime
-    o[9] = (uint32_t)t_load, o[10] = (uint32_t)t_fwd, o[11] = (uint32_t)t_mac, o[12] = (uint32_t)t_inv, o[13] = (uint32_t)t_fin;
+    o[9] = (uint32_t)t_load, o[10] = (uint32_t)t_fwd, o[11] = (uint32_t)t_mac, o[12] = (uint32_t)t_inv, o[13] = (uint32_t)t_fin, o[14] = (uint32_t)t_rot;
   }
 #endif
 }

@@ -62,10 +62,10 @@ life = e - s
 print("life  us: min %.2f p50 %.2f max %.2f ; slot busy fraction %.3f" % (life.min(), np.median(life), life.max(), life.sum() / (len(s) * e.max())))
 cyc = lines[:, 8].astype(np.float64)
 print("shader clock over the wave lifetimes: median %.3f GHz (min %.3f max %.3f)" % (np.median(cyc / life) / 1e3, (cyc / life).min() / 1e3, (cyc / life).max() / 1e3))
-sec = lines[:, 9:14].astype(np.float64)
+sec = lines[:, 9:15].astype(np.float64)
 tot = cyc.mean()
-print("wall cycles per wave: lifetime %.0f ; load_lift %.0f (%.0f%%)  wave_fwd %.0f (%.0f%%)  mac %.0f (%.0f%%)  inverse+fold %.0f (%.0f%%)  finish_row %.0f (%.0f%%)" % (
-    tot, *sum(([sec[:, i].mean(), 100 * sec[:, i].mean() / tot] for i in range(5)), [])))
+print("wall cycles per wave: lifetime %.0f ; load_lift %.0f (%.0f%%)  wave_fwd %.0f (%.0f%%)  mac %.0f (%.0f%%)  inverse+fold %.0f (%.0f%%)  finish_row %.0f (%.0f%%)  rotation terms %.0f (%.0f%%)" % (
+    tot, *sum(([sec[:, i].mean(), 100 * sec[:, i].mean() / tot] for i in range(6)), [])))
 hw = lines[:, 4]
 xcc = lines[:, 5] & 0xf
 cu = (hw >> 8) & 0xf

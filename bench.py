@@ -204,16 +204,54 @@ def cpu_baseline(workload, N, n, k, l, V, seconds):
     }
 
 
+def self_launch(ngpus):
+    """`python bench.py --gpus N` (N > 1) started WITHOUT torch.distributed.run: this process becomes a plain parent that
+    starts the N ranks as a fresh child (`python -m torch.distributed.run ... bench.py <same args>`), relays the
+    child's output (rank 0 prints the JSON line) and exits with the child's status.  The parent never imports torch
+    or touches a HIP device: a process that has initialised the GPU must not start GPU children on this pool."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+    env["RZK_BENCH_SELF_LAUNCHED"] = "1"
+    print(f"bench.py: --gpus {ngpus} without a launcher: starting {ngpus} ranks through torch.distributed.run "
+          f"(127.0.0.1:{port})", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if os.environ.get("RZK_BENCH_JOIN_ONLY"):
+        # CPU-tier rehearsal of the launch path (tests/test_bench_launch.py): every rank joins the process group,
+        # takes part in one reduction and leaves — no GPU needed, nothing measured
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("RZK_BENCH_BACKEND", "gloo"), rank=rank, world_size=world)
+        from ring_zk_amd import shard
+
+        el, tot, per_rank = shard.reduce_result(dist, 1.0 + rank, rank + 1, torch.device("cpu"), gather=True)
+        if rank == 0:
+            print(json.dumps({"joined": world, "max_elapsed": el, "sum": tot, "per_rank": per_rank,
+                              "self_launched": bool(os.environ.get("RZK_BENCH_SELF_LAUNCHED"))}), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     # RZK_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than ranks (ranks
     # share devices, reductions run on CPU tensors).  The real multi-GPU run uses nccl (= RCCL over xGMI).
@@ -498,8 +536,13 @@ def main():
                 ntt["cpu_same_algorithm"] = cpu_ntt(N, ctx.ntt_prime(0), ctx.ntt_psi(0))
 
     cpu = None
+    cpu_reason = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.workload, N, n, k, l, V, args.cpu_seconds)
+    elif world > 1:
+        cpu_reason = "timed on rank 0 at N=1 only (the host cores are shared by all ranks of a multi-GPU run)"
+    else:
+        cpu_reason = "--no-cpu-baseline"
 
     if rank == 0:
         out = {
@@ -536,6 +579,7 @@ def main():
             "units": units,
             "ntt_roofline": ntt,
             "cpu_baseline": cpu,
+            "cpu_baseline_skipped": cpu_reason,
         }
         print(json.dumps(out))
     if dist is not None:

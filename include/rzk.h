@@ -49,6 +49,12 @@ extern "C" {
 
 typedef struct rzk_ctx rzk_ctx;
 
+/* Version of this C ABI: bumped whenever an existing signature changes (rzk_wire_mat_decode gained `q` in 2,
+ * version 3 added the entry points marked "v3").  A binding checks rzk_abi_version() == RZK_ABI_VERSION after loading
+ * the library, so that a stale or variant .so fails at load time instead of reading shifted arguments. */
+#define RZK_ABI_VERSION 3u
+uint32_t rzk_abi_version(void);
+
 /* Which block of the commitment key a matrix-vector product uses (src/commit.rs:19-25). */
 #define RZK_KEY_A1 0 /* a1: n x k        (rows 0..n-1 of [a1;a2])  */
 #define RZK_KEY_A2 1 /* a2: l x k        (rows n..n+l-1)           */
@@ -70,11 +76,22 @@ void rzk_ctx_destroy(rzk_ctx* ctx);
  * (null) stream.  rzk_ctx_use_own_stream goes back to the private stream created with the context. */
 int rzk_ctx_set_stream(rzk_ctx* ctx, void* hip_stream);
 int rzk_ctx_use_own_stream(rzk_ctx* ctx);
+/* v3.  Trusted-producer mode, default OFF.  With on != 0 the caller vouches that every coefficient later calls on this
+ * context load is canonical — written by this library on this device (commitments, t, responses, sampler outputs), or
+ * validated before (rzk_canonicalize_batch, rzk_wire_mat_decode with q) — and the kernels skip the per-coefficient
+ * range test (3 vector instructions per loaded coefficient).  Norm predicates, the norm measurements that fix the
+ * prime count, and therefore the results on canonical data are unchanged; on non-canonical data the results are
+ * unspecified.  A verifier that receives z, t, c from elsewhere leaves this off (reference: ZqI64::from,
+ * src/params.rs:126, makes every value canonical by construction).  Synchronises the stream. */
+int rzk_ctx_trust_device_outputs(rzk_ctx* ctx, int on);
 /* Waits for the context's stream.  Also the point where the asynchronous *_dev calls report non-canonical input
  * coefficients (see "Conventions"): RZK_E_ARG once, then the condition is cleared.  rzk_ctx_check_inputs is the
  * same call under the name a caller uses when it only wants that verdict. */
 int rzk_ctx_synchronize(rzk_ctx* ctx);
 int rzk_ctx_check_inputs(rzk_ctx* ctx);
+/* Ordering rule for mixed use: a host-pointer call reports only its OWN input faults — it clears the sticky condition
+ * when it starts.  A caller of *_dev entry points that wants their verdict must therefore ask for it
+ * (rzk_ctx_check_inputs / rzk_ctx_synchronize) before its next host-pointer call on the same context. */
 /* Message of the last failure on this context; with ctx == NULL, of the last failed rzk_ctx_create. */
 const char* rzk_last_error(const rzk_ctx* ctx);
 /* sigma, 4*sigma*floor(sqrt N), 2*sigma*floor(sqrt N)   (src/params.rs:94-98,104,114) */
@@ -282,6 +299,25 @@ int rzk_prof_read(rzk_ctx* ctx, double* row_kernel_us, uint64_t* row_kernel_laun
  * durations in launch order (synchronises; does not clear) */
 uint64_t rzk_prof_count(const rzk_ctx* ctx);
 int rzk_prof_read_all(rzk_ctx* ctx, double* us, size_t cap, size_t* count);
+/* v3.  Which kernel every recorded launch ran and its algorithmic bytes (8 N x (distinct polynomials the row program
+ * reads + rows it stores) x batch entries), one "<kernel>\t<bytes>\n" line per launch in launch order; *needed = length
+ * of the full text.  bench.py names the dominant kernel of every configuration with this. */
+int rzk_prof_read_kernels(rzk_ctx* ctx, char* buf, size_t cap, size_t* needed);
+
+/* ---- environment variables (read once by rzk_ctx_create) ----------------------------------------------------------
+ * Testing / tuning switches, NOT part of the API contract: every setting computes the same results; they select which
+ * kernel evaluates a row program so that the test-suite can reach every kernel at small shapes and so that A/B
+ * measurements need no rebuild.  Defaults are what the measurements in DESIGN.md §6 chose.
+ *   RZK_SHIFT=0            challenge products through transforms instead of signed rotations (default 1; N <= 1024)
+ *   RZK_PAIRS=0            unit_kernel: no pairing of rows that share their last operand (default 1)
+ *   RZK_UPT=<u>            unit_kernel: units of a proof per wavefront task (default: all once batch >= 16 x CUs, else 1)
+ *   RZK_VEC_ROWS=0         programs with vector x vector products through unit_kernel instead of row_kernel (default 1)
+ *   RZK_ROW_GROUPS=0       no row groups (row_group_kernel) for key blocks with n > 1 (default 1)
+ *   RZK_GROUP_MAX=<g>      rows per group, 1 .. 4 (default 4 at N <= 1024, 1 at N = 2048)
+ *   RZK_BLOCK_MIN_LOGN=<L> row blocks (row_block_kernel) from ring degree 2^L on (default 11; 12 = never, 10 = also N = 1024)
+ *   RZK_SLOT_SHARE_MIN=<x> shared-operand path when (operand transforms) / (distinct operands) >= x (default 2.0; 0 = never)
+ *   RZK_PAIR_POLY=0        N = 2048: one wavefront per polynomial instead of two (default 1)
+ * RZK_LIB (ring_zk_amd/_lib.py, Python only) loads another build of the library for A/B runs. */
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,8 @@ SIGNATURES = {
     "rzk_ctx_create": (C.c_int, [C.POINTER(_CTX), C.c_int64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                  C.c_uint32, C.c_uint64, C.c_int]),
     "rzk_ctx_destroy": (None, [_CTX]),
+    "rzk_abi_version": (C.c_uint32, []),
+    "rzk_ctx_trust_device_outputs": (C.c_int, [_CTX, C.c_int]),
     "rzk_ctx_set_stream": (C.c_int, [_CTX, C.c_void_p]),
     "rzk_ctx_use_own_stream": (C.c_int, [_CTX]),
     "rzk_ctx_synchronize": (C.c_int, [_CTX]),
@@ -74,7 +76,9 @@ SIGNATURES = {
     "rzk_prof_read": (C.c_int, [_CTX, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "rzk_prof_count": (C.c_uint64, [_CTX]),
     "rzk_prof_read_all": (C.c_int, [_CTX, C.POINTER(C.c_double), _SZ, C.POINTER(C.c_size_t)]),
+    "rzk_prof_read_kernels": (C.c_int, [_CTX, C.c_char_p, _SZ, C.POINTER(C.c_size_t)]),
 }
+ABI_VERSION = 3   # include/rzk.h: RZK_ABI_VERSION
 # every batched entry point also exists as a device-pointer variant with the same signature
 for _name in list(SIGNATURES):
     if _name.endswith("_batch"):
@@ -95,13 +99,17 @@ def lib() -> C.CDLL:
         except ImportError:
             pass
         L = C.CDLL(SO)
+        # a stale or variant library with another ABI must fail here, not read shifted arguments later
+        try:
+            L.rzk_abi_version.restype = C.c_uint32
+            have = int(L.rzk_abi_version())
+        except AttributeError:
+            have = None
+        if have != ABI_VERSION:
+            raise RuntimeError(f"{SO}: C ABI version {have}, this binding needs {ABI_VERSION} (include/rzk.h); rebuild with "
+                               "`python -m ring_zk_amd.build`")
         for name, (res, args) in SIGNATURES.items():
-            try:
-                f = getattr(L, name)  # AttributeError if the library does not export a declared symbol
-            except AttributeError:
-                if "RZK_LIB" in os.environ:   # tuning / comparison variants (tools/) may predate a symbol
-                    continue
-                raise
+            f = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             f.restype = res
             f.argtypes = args
         _lib = L

@@ -274,6 +274,22 @@ class Context:
         self._check(self._L.rzk_prof_read_all(self._h, buf, n, C.byref(cnt)))
         return [buf[i] for i in range(min(n, cnt.value))]
 
+    def prof_read_kernels(self):
+        """[(kernel template instance, algorithmic bytes)] of the recorded launches, in launch order."""
+        need = C.c_size_t(0)
+        self._check(self._L.rzk_prof_read_kernels(self._h, None, 0, C.byref(need)))
+        buf = C.create_string_buffer(need.value + 1)
+        self._check(self._L.rzk_prof_read_kernels(self._h, buf, need.value + 1, C.byref(need)))
+        out = []
+        for line in buf.value.decode().splitlines():
+            name, nbytes = line.rsplit("\t", 1)
+            out.append((name, int(nbytes)))
+        return out
+
+    def trust_device_outputs(self, on=True):
+        """Trusted-producer mode (rzk_ctx_trust_device_outputs): skip the canonical test of loaded coefficients."""
+        self._check(self._L.rzk_ctx_trust_device_outputs(self._h, 1 if on else 0))
+
     # ---- device-side samplers (statistical parity with src/polynomial.rs:14-44, src/challenge_space.rs:12-33) ----
     def _sample_out(self, lead):
         import torch

@@ -59,7 +59,6 @@ struct DevProg {
   WaveProgram* d_wp = nullptr;   // units / items of unit_kernel (the default path)
   uint32_t nunits = 0;
   uint32_t work = 0;             // steps (item + inverse trips) of one batch entry per prime pass
-  uint32_t nsplit = 0;           // units that are candidates for split_kernel
   bool has_vec = false;
   // shared-operand path (fwd_slots_kernel + row_slots_kernel), chosen when rows share enough operands
   SlotTable* d_slots = nullptr;
@@ -71,6 +70,9 @@ struct DevProg {
   bool two_bit = false;   // two-bit verdict flags (CHECK2 marks)
   BlockPlan* d_blocks = nullptr;   // row blocks (row_block_kernel): operands of a block staged once in LDS
   uint32_t nblocks = 0;
+  // algorithmic traffic of one batch entry (instrumentation): distinct polynomials read per operand index, rows stored
+  uint16_t polys_in[kMaxOperands] = {};
+  uint32_t polys_out = 0;
 };
 
 struct Arena {   // grow-only device buffer
@@ -99,8 +101,7 @@ struct rzk_ctx {
   bool use_groups = true;
   uint32_t units_per_task = 0;         // 0 = automatic (RZK_UPT overrides, tuning)
   bool vec_rows = true;                // programs with vector x vector products: row_kernel (RZK_VEC_ROWS=0: unit_kernel)
-  bool use_split = false;              // split_kernel for key products with small-norm operands: measured slower than
-                                       // unit_kernel's two-prime pairs; RZK_SPLIT=1 turns it on
+  bool trusted = false;                // rzk_ctx_trust_device_outputs: skip the canonical test of loaded coefficients
   bool use_pairs = true;               // unit_kernel: pair rows that share their last operand (RZK_PAIRS=0 turns it off, tuning)
   int group_max = 1;                   // rows per group of row_group_kernel (group_max_for; RZK_GROUP_MAX overrides, tuning)
   bool use_shift = true;               // challenge products as signed rotations (shift_row_kernel) instead of transforms
@@ -113,9 +114,9 @@ struct rzk_ctx {
   std::vector<int32_t> key_entry;     // index into the NTT-domain store, -1 if not GENERAL
   uint32_t n_general = 0;
   uint32_t* d_key_ntt = nullptr;
-  double* d_key_inf = nullptr;
+  double* d_key_l2 = nullptr;
   std::map<std::pair<int, uint32_t>, DevProg> progs;
-  Arena ws, stage, ws_slots, ws_done;
+  Arena ws, stage, ws_slots;
   // canonical-input test (rzk_dev.h, Operands::bad): sticky word set by any kernel that loaded a coefficient
   // outside the centred range on behalf of an entry point without per-proof verdicts; read back at every
   // synchronising call (host-pointer variants, rzk_ctx_synchronize, rzk_ctx_check_inputs)
@@ -126,6 +127,11 @@ struct rzk_ctx {
   // profiling of the row kernel with HIP events on the launch stream
   bool prof = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+  struct ProfInfo {
+    std::string kernel;     // the kernel template instance the launch ran
+    uint64_t bytes = 0;     // algorithmic bytes of the launch: 8 N x (distinct polynomials read + rows stored)
+  };
+  std::vector<ProfInfo> prof_info;   // parallel to the used part of prof_events
   size_t prof_used = 0;
   double prof_us = 0.0;
   uint64_t prof_launches = 0;
@@ -185,7 +191,6 @@ struct PB {
   bool overflow = false;
   bool two_bit = false;      // the program carries CHECK2 marks: two-bit verdict flags (row_kernel only)
   uint32_t sparse_ops = 0;   // bit i: operand i is a challenge (kappa-sparse, +-1): products with it may use shift-add
-  uint32_t small_ops = 0;    // bit i: operand i is expected to have a small 1-norm (commitment randomness): split_kernel
   int cur = -1;
   void begin_row(uint8_t out_op, uint32_t out_off, uint8_t mode) {
     if (p.nrows >= (uint32_t)kMaxRows) { overflow = true; return; }
@@ -326,7 +331,6 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
       }
       break;
     case PG_OPEN_COMMIT:   // ops: 0 = x[l], 1 = r[k], 2 = y[k], 3 = c[n+l], 4 = t[n]
-      pb.small_ops = 1u << 1;
       for (uint32_t i = 0; i < n + l; ++i) {   // commit.rs:125: c = [a1;a2].r + [0_n ; x]
         pb.begin_row(3, i, MODE_STORE);
         key_row(c, pb, +1, i, 1, 0);
@@ -341,7 +345,6 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
       }
       break;
     case PG_COMMIT:   // ops: 0 = x[l], 1 = r[k], 2 = c[n+l]
-      pb.small_ops = 1u << 1;
       for (uint32_t i = 0; i < n + l; ++i) {   // commit.rs:109-125
         pb.begin_row(2, i, MODE_STORE);
         key_row(c, pb, +1, i, 1, 0);
@@ -352,7 +355,6 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
       }
       break;
     case PG_COMMIT_VERIFY:   // ops: 0 = x[l], 1 = r[k], 2 = c[n+l], 3 = f ; flags &= (commit.rs:199-209)
-      if (!(var & 2)) pb.small_ops = 1u << 1;
       for (uint32_t i = 0; i < n + l; ++i) {
         pb.begin_row(0, 0, MODE_ZERO);
         key_row(c, pb, +1, i, 1, 0);
@@ -411,7 +413,6 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
     case PG_LIN_COMMIT2:
       // ops: 0 = x[l], 1 = gx[l], 2 = r[k], 3 = rp[k], 4 = y[k], 5 = yp[k],
       //      6 = c[n+l], 7 = cp[n+l], 8 = t[n], 9 = tp[n], 10 = a2y[l]
-      pb.small_ops = (1u << 2) | (1u << 3);
       for (uint32_t i = 0; i < n + l; ++i) {   // linear.rs:97: c = commit(x; r)
         pb.begin_row(6, i, MODE_STORE);
         key_row(c, pb, +1, i, 2, 0);
@@ -694,26 +695,14 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
           }
         }
       }
-      // split candidates: one or two key products, every operand hinted small, no rotation terms (those use the
-      // st_sh scratch line protocol of unit_kernel)
-      if (c->use_split && ra.nterms >= 1 && ra.nterms <= 2 && ra.nshift == 0 && key_only(ra) &&
-          (un.rowB == kNoRow || pb.p.rows[r + 1].nshift == 0)) {
-        bool small = true;
-        for (uint32_t t = 0; t < ra.nterms; ++t) small = small && ((pb.small_ops >> pb.p.terms[ra.term0 + t].b_op) & 1u);
-        if (small) {
-          wp.split_units[wp.nsplit++] = (uint16_t)(wp.nunits - 1);
-          un.nitems |= kUnitSplit;
-        }
-      }
       r += step;
     }
-    dp.nsplit = wp.nsplit;
     HIPCHK(c, hipMalloc((void**)&dp.d_wp, sizeof(WaveProgram)));
     HIPCHK(c, hipMemcpyAsync(dp.d_wp, &wp, sizeof(WaveProgram), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     dp.nunits = wp.nunits;
     for (uint32_t u = 0; u < wp.nunits; ++u)
-      dp.work += ((wp.units[u].nitems & kUnitItemsMask) ? (wp.units[u].nitems & kUnitItemsMask) : 1u) + (wp.units[u].rowB != kNoRow ? 2u : 1u);
+      dp.work += (wp.units[u].nitems ? wp.units[u].nitems : 1u) + (wp.units[u].rowB != kNoRow ? 2u : 1u);
   }
   for (uint32_t t = 0; t < pb.p.nterms; ++t) dp.has_vec = dp.has_vec || (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_VEC;
   // distinct operands of the product terms ("slots"); when rows share them often enough, transform each
@@ -753,6 +742,25 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
       HIPCHK(c, hipStreamSynchronize(c->stream));
       dp.nslots = st.nslots;
       dp.np_store = dp.has_vec ? 3 : 2;
+    }
+  }
+  {
+    std::map<std::pair<uint32_t, uint32_t>, int> seen;
+    auto touch = [&](uint32_t op, uint32_t off) {
+      if (op < (uint32_t)kMaxOperands && !seen.count({op, off})) {
+        seen[{op, off}] = 1;
+        dp.polys_in[op]++;
+      }
+    };
+    for (uint32_t r = 0; r < pb.p.nrows; ++r) {
+      const Row& row = pb.p.rows[r];
+      for (uint32_t t = 0; t < (uint32_t)row.nterms + row.nshift; ++t) {
+        const Term& tm = pb.p.terms[row.term0 + t];
+        touch(tm.b_op, tm.b_off);
+        if ((tm.kind & TERM_KIND_MASK) != TERM_KEY) touch(tm.a_op, tm.a_off);
+      }
+      for (uint32_t a = 0; a < row.nadds; ++a) touch(pb.p.adds[row.add0 + a].op & ADD_OP_MASK, pb.p.adds[row.add0 + a].off);
+      if (row.mode == MODE_STORE) dp.polys_out++;
     }
   }
   c->progs[{id, var}] = dp;
@@ -795,6 +803,7 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
   ops.pad = dp.two_bit ? 1 : 0;
   ops.norm_limit = norm_limit;
   ops.bad = sticky ? c->d_bad : nullptr;
+  ops.trusted = c->trusted ? 1u : 0u;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->prof) {
     if (c->prof_used == c->prof_events.size()) {
@@ -807,6 +816,20 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
     }
     e0 = c->prof_events[c->prof_used].first;
     e1 = c->prof_events[c->prof_used].second;
+    if (c->prof_info.size() <= c->prof_used) c->prof_info.resize(c->prof_used + 1);
+    rzk_ctx::ProfInfo& pi = c->prof_info[c->prof_used];
+    const std::string L = std::to_string(c->logn);
+    if (c->small) pi.kernel = "row_kernel_small";
+    else if (dp.shift) pi.kernel = "shift_row_kernel<" + L + ">";
+    else if (dp.nblocks) pi.kernel = "row_block_kernel<" + L + ">";
+    else if (dp.ngroups) pi.kernel = "row_group_kernel<" + L + ", " + std::to_string(c->logn >= 11 ? 2 : RZK_GROUP_GM) + ">";
+    else if (dp.d_slots) pi.kernel = "fwd_slots_kernel<" + L + "> + row_slots_kernel<" + L + ">";
+    else if (dp.has_vec && c->vec_rows) pi.kernel = "row_kernel<" + L + ", " + (dp.has_shift ? "true" : "false") + ">";
+    else pi.kernel = "unit_kernel<" + L + ", " + (dp.has_vec ? "true" : "false") + ", " + (dp.has_shift ? "true" : "false") + ">";
+    pi.bytes = 0;
+    for (size_t i = 0; i < specs.size(); ++i)
+      pi.bytes += (uint64_t)dp.polys_in[i] * (specs[i].outer ? batch / (group ? group : 1) : batch);
+    pi.bytes = (pi.bytes + (uint64_t)dp.polys_out * batch) * 8ull * c->N;
     c->prof_used++;
     HIPCHK(c, hipEventRecord(e0, c->stream));
   }
@@ -818,12 +841,12 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
   } else if (dp.nblocks) {
     if (!c->d_block_scratch)
       HIPCHK(c, hipMalloc((void**)&c->d_block_scratch, block_scratch_words((int)c->logn, c->num_cus) * sizeof(uint32_t)));
-    lrc = launch_row_blocks((int)c->logn, cfg_of(c), dp.d, dp.d_blocks, dp.nblocks, ops, c->d_key_ntt, c->d_key_inf, c->dT,
+    lrc = launch_row_blocks((int)c->logn, cfg_of(c), dp.d, dp.d_blocks, dp.nblocks, ops, c->d_key_ntt, c->d_key_l2, c->dT,
                             c->d_tw, c->d_block_scratch, flags, batch);
   } else if (dp.ngroups) {
     if (!c->d_group_scratch)
       HIPCHK(c, hipMalloc((void**)&c->d_group_scratch, group_scratch_words((int)c->logn, c->num_cus) * sizeof(uint32_t)));
-    lrc = launch_row_groups((int)c->logn, cfg_of(c), dp.d, dp.ngroups, ops, c->d_key_ntt, c->d_key_inf, c->dT, c->d_tw,
+    lrc = launch_row_groups((int)c->logn, cfg_of(c), dp.d, dp.ngroups, ops, c->d_key_ntt, c->d_key_l2, c->dT, c->d_tw,
                             c->d_group_scratch, flags, batch);
   } else if (dp.d_slots) {
     // shared-operand path; the workspace of stored transforms is bounded, so large batches go in chunks
@@ -847,7 +870,7 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
         o2.base[i] += first * o2.stride[i] * c->N;
       }
       lrc = launch_row_program_slots((int)c->logn, cfg_of(c), dp.d, dp.d_slots, dp.nslots, o2, c->d_key_ntt,
-                                     c->d_key_inf, c->dT, c->d_tw, d_ws, d_norms, c->d_row_scratch,
+                                     c->d_key_l2, c->dT, c->d_tw, d_ws, d_norms, c->d_row_scratch,
                                      flags ? flags + b0 / grp : nullptr, nb, dp.np_store);
     }
   } else {
@@ -855,21 +878,12 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
     // the chip's wave slots; one unit per task below that
     uint32_t upt = batch >= (uint64_t)c->num_cus * 16 ? dp.nunits : 1;
     if (c->units_per_task) upt = c->units_per_task;   // RZK_UPT (tuning)
-    uint8_t* d_done = nullptr;
     if (dp.has_vec && c->vec_rows) {
-      lrc = launch_rows((int)c->logn, cfg_of(c), dp.d, dp.nrows, dp.has_shift, ops, c->d_key_ntt, c->d_key_inf, c->dT, c->d_tw,
+      lrc = launch_rows((int)c->logn, cfg_of(c), dp.d, dp.nrows, dp.has_shift, ops, c->d_key_ntt, c->d_key_l2, c->dT, c->d_tw,
                         c->d_row_scratch, flags, batch);
     } else {
-    if (dp.nsplit) {   // small-norm operands first (split_kernel marks what it finished), everything else after
-      int rc2 = arena_reserve(c, c->ws_done, (size_t)batch * dp.nunits);
-      if (rc2 != RZK_OK) return rc2;
-      d_done = (uint8_t*)c->ws_done.p;
-      lrc = launch_split((int)c->logn, cfg_of(c), dp.d, dp.d_wp, dp.nsplit, ops, c->d_key_ntt, c->d_key_inf, c->dT, c->d_tw,
-                         c->d_row_scratch, flags, d_done, batch);
-    }
-    if (lrc == 0)
       lrc = launch_units((int)c->logn, cfg_of(c), dp.d, dp.d_wp, dp.nunits, upt, 2 * dp.work, dp.has_vec, dp.has_shift, ops,
-                         c->d_key_ntt, c->d_key_inf, c->dT, c->d_tw, c->d_row_scratch, flags, batch, d_done);
+                         c->d_key_ntt, c->d_key_l2, c->dT, c->d_tw, c->d_row_scratch, flags, batch);
     }
   }
   if (lrc == -2) return fail(c, RZK_E_UNSUPPORTED, "batch * rows must stay below 2^32");
@@ -1044,7 +1058,6 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
   if (const char* e = std::getenv("RZK_SHIFT")) c->use_shift = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_PAIRS")) c->use_pairs = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_UPT")) c->units_per_task = (uint32_t)std::atoi(e);
-  if (const char* e = std::getenv("RZK_SPLIT")) c->use_split = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_VEC_ROWS")) c->vec_rows = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_BLOCK_MIN_LOGN")) c->block_min_logn = (uint32_t)std::atoi(e);   // 12 = never
 
@@ -1087,10 +1100,9 @@ void rzk_ctx_destroy(rzk_ctx* c) {
     (void)hipEventDestroy(ev.second);
   }
   if (c->d_key_ntt) (void)hipFree(c->d_key_ntt);
-  if (c->d_key_inf) (void)hipFree(c->d_key_inf);
+  if (c->d_key_l2) (void)hipFree(c->d_key_l2);
   if (c->ws.p) (void)hipFree(c->ws.p);
   if (c->ws_slots.p) (void)hipFree(c->ws_slots.p);
-  if (c->ws_done.p) (void)hipFree(c->ws_done.p);
   if (c->stage.p) (void)hipFree(c->stage.p);
   if (c->dT) (void)hipFree(c->dT);
   if (c->d_tw) (void)hipFree(c->d_tw);
@@ -1102,6 +1114,15 @@ void rzk_ctx_destroy(rzk_ctx* c) {
   if (c->h_bad) (void)hipHostFree(c->h_bad);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
+}
+
+uint32_t rzk_abi_version(void) { return RZK_ABI_VERSION; }
+
+int rzk_ctx_trust_device_outputs(rzk_ctx* c, int on) {
+  if (!c) return RZK_E_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->trusted = on != 0;
+  return RZK_OK;
 }
 
 int rzk_ctx_set_stream(rzk_ctx* c, void* hip_stream) {
@@ -1146,13 +1167,12 @@ static int key_load_impl(rzk_ctx* c, const int64_t* a_host) {
   for (size_t e = 0; e < total; ++e) {
     const int64_t* p = a_host + e * N;
     bool tail_zero = true;
-    int64_t mx = 0;
+    long double ssq = 0.0L;
     for (uint32_t j = 0; j < N; ++j) {
       const int64_t v = p[j];
       if (v > half || v < -half) return fail(c, RZK_E_ARG, "key coefficient outside the centred range");
       if (j > 0 && v != 0) tail_zero = false;
-      const int64_t a = v < 0 ? -v : v;
-      if (a > mx) mx = a;
+      ssq += (long double)v * (long double)v;
     }
     if (tail_zero && p[0] == 0)
       c->key_class[e] = KC_ZERO;
@@ -1161,15 +1181,15 @@ static int key_load_impl(rzk_ctx* c, const int64_t* a_host) {
     else {
       c->key_entry[e] = (int32_t)c->n_general++;
       general.insert(general.end(), p, p + N);
-      kinf.push_back((double)mx);
+      kinf.push_back((double)(std::sqrt(ssq) * (1.0L + 1e-6L)));   // upper bound of the entry's 2-norm (prime-count bound), still one after rounding to float
     }
   }
   drop_programs(c);   // programs depend on the classification
   if (c->d_key_ntt) HIPCHK(c, hipFree(c->d_key_ntt));
-  if (c->d_key_inf) HIPCHK(c, hipFree(c->d_key_inf));
+  if (c->d_key_l2) HIPCHK(c, hipFree(c->d_key_l2));
   if (c->d_key_mont) HIPCHK(c, hipFree(c->d_key_mont));
   c->d_key_ntt = nullptr;
-  c->d_key_inf = nullptr;
+  c->d_key_l2 = nullptr;
   c->d_key_mont = nullptr;
   if (c->n_general && c->small) {
     const size_t gbytes = general.size() * sizeof(int64_t);
@@ -1187,9 +1207,9 @@ static int key_load_impl(rzk_ctx* c, const int64_t* a_host) {
     int rc = arena_reserve(c, c->stage, gbytes);
     if (rc != RZK_OK) return rc;
     HIPCHK(c, hipMalloc((void**)&c->d_key_ntt, (size_t)c->n_general * kKeyImages * N * sizeof(uint32_t)));
-    HIPCHK(c, hipMalloc((void**)&c->d_key_inf, (size_t)c->n_general * sizeof(double)));
+    HIPCHK(c, hipMalloc((void**)&c->d_key_l2, (size_t)c->n_general * sizeof(double)));
     HIPCHK(c, hipMemcpyAsync(c->stage.p, general.data(), gbytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_key_inf, kinf.data(), kinf.size() * sizeof(double), hipMemcpyHostToDevice,
+    HIPCHK(c, hipMemcpyAsync(c->d_key_l2, kinf.data(), kinf.size() * sizeof(double), hipMemcpyHostToDevice,
                              c->stream));
     rc = check_launch(c, launch_key_transform((int)c->logn, cfg_of(c), (const int64_t*)c->stage.p, c->n_general,
                                               c->d_key_ntt, c->dT, c->d_tw),
@@ -1626,13 +1646,22 @@ int rzk_sum_verify_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* zs, const in
 #define IN(ptr, bytes) HostBuf{(ptr), nullptr, (bytes), nullptr}
 #define OUT(ptr, bytes) HostBuf{nullptr, (ptr), (bytes), nullptr}
 #define DEV(i, T) ((T)bufs[i].dev)
-#define HOST_WRAP(call)                      \
-  do {                                       \
-    int rc_ = stage_in(c, bufs);             \
-    if (rc_ != RZK_OK) return rc_;           \
-    rc_ = (call);                            \
-    if (rc_ != RZK_OK) return rc_;           \
-    return stage_out(c, bufs);               \
+// A host-pointer call reports exactly its own input faults: the sticky word is cleared on the stream before the call's
+// work (a fault left by earlier *_dev calls whose caller never asked — rzk_ctx_check_inputs — is dropped here, as
+// include/rzk.h documents) and consumed again when the call fails half-way, so it never leaks into the next call.
+#define HOST_WRAP(call)                                                                    \
+  do {                                                                                     \
+    HIPCHK(c, hipMemsetAsync(c->d_bad, 0, sizeof(uint32_t), c->stream));                   \
+    int rc_ = stage_in(c, bufs);                                                           \
+    if (rc_ != RZK_OK) return rc_;                                                         \
+    rc_ = (call);                                                                          \
+    if (rc_ != RZK_OK) {                                                                   \
+      const std::string keep_ = c->err;                                                    \
+      (void)take_input_error(c);                                                           \
+      c->err = keep_;                                                                      \
+      return rc_;                                                                          \
+    }                                                                                      \
+    return stage_out(c, bufs);                                                             \
   } while (0)
 
 int rzk_polymul_batch(rzk_ctx* c, const int64_t* a, const int64_t* b, int64_t* out, size_t count) {
@@ -1906,6 +1935,22 @@ int rzk_prof_read_all(rzk_ctx* c, double* us, size_t cap, size_t* count) {
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->prof_events[i].first, c->prof_events[i].second));
     us[i] = (double)ms * 1000.0;
+  }
+  return RZK_OK;
+}
+
+// One line per recorded launch, in launch order: "<kernel>\t<algorithmic bytes>\n".  Returns the text's length through
+// *needed (without the terminating NUL); copies at most cap - 1 characters.
+int rzk_prof_read_kernels(rzk_ctx* c, char* buf, size_t cap, size_t* needed) {
+  if (!c || (!buf && cap)) return RZK_E_ARG;
+  std::string text;
+  for (size_t i = 0; i < c->prof_used && i < c->prof_info.size(); ++i)
+    text += c->prof_info[i].kernel + "\t" + std::to_string(c->prof_info[i].bytes) + "\n";
+  if (needed) *needed = text.size();
+  if (cap) {
+    const size_t ncopy = text.size() < cap - 1 ? text.size() : cap - 1;
+    std::memcpy(buf, text.data(), ncopy);
+    buf[ncopy] = 0;
   }
   return RZK_OK;
 }

@@ -52,13 +52,7 @@
 namespace rzk {
 
 constexpr int kMaxPrimes = 3;
-// Resident images of a key entry K in the NTT domain: one per auxiliary prime, plus the two HALVES of K under prime 0
-// (K = Klo + 2^16 Khi, |Klo|, |Khi| <= 2^15).  A product of K with operands of small 1-norm (the ternary randomness of
-// a commitment, commit.rs:98-107) fits ONE prime per half — 2^15 |v|_1 <= (p0-1)/2 — so such rows need one forward
-// transform per operand instead of two and no Garner step: value = Rlo + 2^16 Rhi.
-constexpr int kKeyImages = kMaxPrimes + 2;
-constexpr int kImgLo = kMaxPrimes, kImgHi = kMaxPrimes + 1;
-constexpr int kSplitShift = 16;
+constexpr int kKeyImages = kMaxPrimes;   // resident images of a key entry in the NTT domain: one per auxiliary prime
 constexpr int kTableLog = 12;            // twiddle tables cover N <= 4096
 constexpr int kTableLen = 1 << kTableLog;
 

@@ -120,18 +120,14 @@ struct alignas(8) Item {
   int8_t signA, signB;
   uint16_t pad;
 };
-constexpr uint16_t kUnitSplit = 0x8000;       // in Unit::nitems: candidate for split_kernel (<= 2 key items, operands hinted small)
-constexpr uint16_t kUnitItemsMask = 0x7fff;
 struct alignas(8) Unit {
   uint16_t rowA, rowB;      // indices into Program::rows; rowB = kNoRow for a single row
-  uint16_t item0, nitems;   // nitems & kUnitItemsMask items from item0 on; kUnitSplit flag
+  uint16_t item0, nitems;   // nitems items from item0 on
 };
 struct WaveProgram {
   uint32_t nunits, nitems;
-  uint32_t nsplit, pad;
   Unit units[kMaxRows];
   Item items[kMaxTerms];
-  uint16_t split_units[kMaxRows];   // indices of the split candidates
 };
 
 // Shared-operand path: the distinct polynomials ("slots") the product terms of a program read, and for
@@ -176,6 +172,11 @@ struct Operands {
   // src/params.rs:122-127): a violation clears the proof's verdict flag when the launch has flags, and sets this
   // sticky word of the context when it is not NULL (prover-side and Mat-level entry points: the call fails).
   uint32_t* bad;
+  // != 0: the caller vouches that every coefficient this launch loads is canonical (written by this library on this
+  // device, or validated before): the canonical test is skipped (rzk_ctx_trust_device_outputs).  Norm predicates and
+  // the norm measurements that fix the prime count are evaluated as always.
+  uint32_t trusted;
+  uint32_t pad2;
 };
 
 // ---- launchers (defined in rzk_kernels.hip) --------------------------------------------------------------------
@@ -188,28 +189,24 @@ struct LaunchCfg {
 // one wavefront per proof: equal-cost tasks, no tail)
 // row_kernel: one wavefront per (batch entry, row); programs with vector x vector products
 int launch_rows(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows, bool has_shift, const Operands& ops,
-                const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* d_T, const uint32_t* d_tw,
+                const uint32_t* d_key_ntt, const double* d_key_l2, const DevTables* d_T, const uint32_t* d_tw,
                 uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch);
-// split_kernel over the program's split candidates; done[b * nunits + unit] = 1 for the units it finished
-int launch_split(int logn, const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, uint32_t nsplit,
-                 const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* d_T,
-                 const uint32_t* d_tw, uint32_t* d_scratch, uint8_t* d_flags, uint8_t* d_done, uint64_t batch);
 // work_per_entry: transforms one batch entry costs at two primes (the progress priorities only need an estimate)
 int launch_units(int logn, const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, uint32_t nunits,
                  uint32_t units_per_task, uint32_t work_per_entry, bool has_vec, bool has_shift, const Operands& ops,
-                 const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* d_T, const uint32_t* d_tw,
-                 uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch, const uint8_t* d_done = nullptr);
+                 const uint32_t* d_key_ntt, const double* d_key_l2, const DevTables* d_T, const uint32_t* d_tw,
+                 uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch);
 int launch_row_program_slots(int logn, const LaunchCfg& cfg, const Program* d_prog, const SlotTable* d_slots,
                              uint32_t nslots, const Operands& ops, const uint32_t* d_key_ntt,
-                             const double* d_key_inf, const DevTables* d_T, const uint32_t* d_tw, uint32_t* d_ws,
+                             const double* d_key_l2, const DevTables* d_T, const uint32_t* d_tw, uint32_t* d_ws,
                              double* d_norms, uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch,
                              uint32_t np_store);
 int launch_row_groups(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t ngroups, const Operands& ops,
-                      const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* d_T, const uint32_t* d_tw,
+                      const uint32_t* d_key_ntt, const double* d_key_l2, const DevTables* d_T, const uint32_t* d_tw,
                       uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch);
 size_t group_scratch_words(int logn, int num_cus);
 int launch_row_blocks(int logn, const LaunchCfg& cfg, const Program* d_prog, const BlockPlan* d_plan, uint32_t nblocks,
-                      const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* d_T,
+                      const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_l2, const DevTables* d_T,
                       const uint32_t* d_tw, uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch);
 size_t block_scratch_words(int logn, int num_cus);
 // rows whose products all have a sparse multiplier (the challenge) as `a` operand: shift-add kernel, no transforms

@@ -57,23 +57,119 @@ __device__ __forceinline__ void wave_inv(uint32_t* x, int lane, uint32_t* lds, c
 }
 
 // ---- wave reductions ------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    uint32_t lo = __shfl_xor((uint32_t)v, off, 64);
-    uint32_t hi = __shfl_xor((uint32_t)(v >> 32), off, 64);
-    v += ((uint64_t)hi << 32) | lo;
-  }
-  return v;
+// Butterfly inside the 16-lane rows with DPP operand modifiers (xor 1, xor 2, half-row mirror, row mirror), then the
+// two row broadcasts of GFX9 (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3): six VALU instructions
+// with the lane exchange folded into the arithmetic, the total in lane 63, handed out as a wave-uniform scalar by
+// v_readlane.  No LDS traffic (the ds_bpermute form of __shfl_xor costs an LDS round trip per step, which a
+// wave that runs alone on its SIMD cannot hide).
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {   // lanes without a source read 0 (the identity of +, max)
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, dpp_u32<CTRL, ROW_MASK>(__builtin_bit_cast(uint32_t, v)));
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140, kDppBcast15 = 0x142,
+              kDppBcast31 = 0x143;
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {   // caller guarantees the total fits 32 bits
+  v += dpp_u32<kDppXor1>(v);
+  v += dpp_u32<kDppXor2>(v);
+  v += dpp_u32<kDppHalfMirror>(v);
+  v += dpp_u32<kDppMirror>(v);
+  v += dpp_u32<kDppBcast15, 0xa>(v);
+  v += dpp_u32<kDppBcast31, 0xc>(v);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {   // v >= 0 in every lane
+  v += dpp_f32<kDppXor1>(v);
+  v += dpp_f32<kDppXor2>(v);
+  v += dpp_f32<kDppHalfMirror>(v);
+  v += dpp_f32<kDppMirror>(v);
+  v += dpp_f32<kDppBcast15, 0xa>(v);
+  v += dpp_f32<kDppBcast31, 0xc>(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    uint32_t o = __shfl_xor(v, off, 64);
-    v = o > v ? o : v;
-  }
-  return v;
+  uint32_t o;
+  o = dpp_u32<kDppXor1>(v), v = o > v ? o : v;
+  o = dpp_u32<kDppXor2>(v), v = o > v ? o : v;
+  o = dpp_u32<kDppHalfMirror>(v), v = o > v ? o : v;
+  o = dpp_u32<kDppMirror>(v), v = o > v ? o : v;
+  o = dpp_u32<kDppBcast15, 0xa>(v), v = o > v ? o : v;
+  o = dpp_u32<kDppBcast31, 0xc>(v), v = o > v ? o : v;
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// exact 64-bit total of per-lane values below 2^56: three 24-bit digits, each summed in 32 bits (64 * 2^24 = 2^30)
+__device__ __forceinline__ uint64_t wave_sum_u56(uint64_t v) {
+  const uint32_t d0 = wave_sum_u32((uint32_t)v & 0xffffffu);
+  const uint32_t d1 = wave_sum_u32((uint32_t)(v >> 24) & 0xffffffu);
+  const uint32_t d2 = wave_sum_u32((uint32_t)(v >> 48));
+  return (uint64_t)d0 + ((uint64_t)d1 << 24) + ((uint64_t)d2 << 48);
+}
+// any 64-bit per-lane values (the exact norm kernels): four 16-bit digits
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+  uint64_t tot = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tot += (uint64_t)wave_sum_u32((uint32_t)(v >> (16 * i)) & 0xffffu) << (16 * i);
+  return tot;
+}
+
+// ---- norms ------------------------------------------------------------------------------------------------------
+// How many auxiliary primes an exact product needs follows from |a (*) b|_inf <= |a|_2 |b|_2 (Cauchy-Schwarz), so the
+// only thing measured per operand is S = sum c^2 — in FLOAT while the coefficients are loaded (v_cvt_f32_i32 +
+// v_fma_f32 per coefficient, both full-rate), reduced with wave_sum_f32.  Rounding: the conversion is correct to
+// 2^-24, the square to 2^-23, every accumulation step to 2^-24 of the running sum, at most 32 + 6 steps: the float
+// total is within a factor (1 +- 2^-18) of S.  kNormSlack = 2^-17 covers that with room.
+//   * prime count: S_up = S_float * (1 + kNormSlack) >= S; the bound only has to be safe, never tight.
+//   * norm predicate (Params::check_*_constraint, sum c^2 < L with L <= 2^48): decided by the float total whenever
+//     it is outside [L (1 - slack), L (1 + slack)], and by exact integer arithmetic (sum_sq_exact) inside, so the
+//     verdict is exact for every input: the boundary cases of the tests (flip exactly at (bound+1)^2) take that path.
+constexpr float kNormSlack = 0x1p-17f;
+template <int E>
+__device__ __forceinline__ float sum_sq_f32(const int32_t* v) {   // wave-uniform float total of sum v^2
+  float ss = 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const float f = (float)v[e];
+    ss = __builtin_fmaf(f, f, ss);
+  }
+  return wave_sum_f32(ss);
+}
+// exact sum over the wave of min(|v|, 2^24)^2, saturated at 2^48 per lane: equals sum v^2 whenever that is below 2^48
+template <int E>
+__device__ __forceinline__ uint64_t sum_sq_exact(const int32_t* v) {
+  uint64_t sq = 0;
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const uint32_t u = (uint32_t)v[e];
+    uint32_t a = v[e] < 0 ? 0u - u : u;   // magnitude in unsigned arithmetic (INT32_MIN included)
+    a = a < (1u << 24) ? a : (1u << 24);
+    sq += (uint64_t)a * a;
+  }
+  sq = sq < (1ull << 48) ? sq : (1ull << 48);
+  return wave_sum_u56(sq);
+}
+// sum v^2 < limit ?  (limit <= 2^48; ss = sum_sq_f32 of the same registers)
+template <int E>
+__device__ __forceinline__ bool norm_below(const int32_t* v, float ss, uint64_t limit) {
+  const double s = (double)ss, lim = (double)limit;
+  if (s * (1.0 + 2.0 * (double)kNormSlack) < lim) return true;
+  if (s * (1.0 - 2.0 * (double)kNormSlack) >= lim) return false;
+  return sum_sq_exact<E>(v) < limit;
+}
+// Wave-uniform floats are kept in scalar registers: the bounds below live through whole prime passes, where every
+// vector register counts (gfx9 has no scalar float ALU, so the arithmetic itself runs on the VALU; v_readfirstlane
+// brings the result back).
+__device__ __forceinline__ float uniform_f32(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+// upper bound of |.|_2 from the float total
+__device__ __forceinline__ float norm2_upper(float ss) {
+  return uniform_f32(__builtin_sqrtf(ss * (1.0f + kNormSlack)) * (1.0f + 0x1p-20f));
+}
+// bound += a * b on wave-uniform non-negative floats (each step is correct to 2^-24; primes_for adds the margin)
+__device__ __forceinline__ float bound_fma(float a, float b, float bound) { return uniform_f32(__builtin_fmaf(a, b, bound)); }
 
 // Verdict of a failed norm predicate.  One-bit flags (two_bit == false): the byte is cleared with a plain store
 // (idempotent, any number of rows may do it).  Two-bit flags: bit 0 or bit 1 is cleared with an agent-scope
@@ -156,46 +252,29 @@ __device__ __forceinline__ const int64_t* operand_ptr(const Operands& ops, uint3
     if (LOGN >= RZK_OPAQUE_LANE_MIN_LOGN || OPQ) asm volatile("" : "+v"(v)); \
   } while (0)
 
-// Load one coefficient polynomial (coalesced phase-1 layout), lift it into prime field `pc` and,
-// on the first prime pass, also return its 1-norm and max-norm (wave-uniform).
-// With want_sq it also returns sum min(|c|, 2^24)^2 over the polynomial, which decides sum c^2 < L exactly for
-// every L <= 2^48 (a clamped coefficient alone already reaches 2^48).
+// Load one coefficient polynomial (coalesced phase-1 layout) and lift it into prime field `pc`.
+// measure (the first prime pass): nrm2 = an upper bound of the polynomial's 2-norm (wave-uniform), and — check — the
+// fused norm predicate sum c^2 < limit, exact (norm_below); unless `trusted`, the same pass proves that every
+// coefficient is canonical (canon_lo_mx).  Later passes re-read the low words only.
 template <int LOGN>
-__device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict__ src, int lane,
-                                          const PrimeConsts& pc, bool want_norms, double& l1, double& linf,
-                                          bool want_sq, uint64_t& sumsq, uint32_t qhalf, bool& fault) {
+__device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict__ src, int lane, const PrimeConsts& pc,
+                                          bool measure, float& nrm2, bool check, uint64_t limit, bool& below,
+                                          uint32_t qhalf, bool trusted, bool& fault) {
   using G = Geo<LOGN>;
   int32_t v[G::E];
-  if (want_norms) {
-    // first prime pass: the loads also prove that the coefficients are canonical (canon_lo) and measure the
-    // polynomial; later passes re-read the low words only
-    uint32_t bad = 0;
+  if (measure) {
+    if (trusted) {
 #pragma unroll
-    for (int e = 0; e < G::E; ++e) v[e] = canon_lo(src[G::j_p1(lane, e)], qhalf, bad);
-    uint64_t sum = 0;
-    uint32_t mx = 0;
+      for (int e = 0; e < G::E; ++e) v[e] = (int32_t)src[G::j_p1(lane, e)];
+    } else {
+      uint32_t bad = 0, mx = 0;
 #pragma unroll
-    for (int e = 0; e < G::E; e += 2) {
-      const uint32_t a0 = (uint32_t)(v[e] < 0 ? -v[e] : v[e]);
-      const uint32_t a1 = (uint32_t)(v[e + 1] < 0 ? -v[e + 1] : v[e + 1]);
-      sum += (uint64_t)a0 + a1;
-      mx = a0 > mx ? a0 : mx;
-      mx = a1 > mx ? a1 : mx;
+      for (int e = 0; e < G::E; ++e) v[e] = canon_lo_mx(src[G::j_p1(lane, e)], qhalf, bad, mx);
+      fault = fault || canon_fail(bad, mx, qhalf);
     }
-    l1 = (double)wave_sum_u64(sum);
-    const uint32_t wmx = wave_max_u32(mx);
-    linf = (double)wmx;
-    fault = fault || __any(bad != 0) || wmx > qhalf;
-    if (want_sq) {
-      uint64_t sq = 0;
-#pragma unroll
-      for (int e = 0; e < G::E; ++e) {
-        uint32_t a = (uint32_t)(v[e] < 0 ? -v[e] : v[e]);
-        a = a < (1u << 24) ? a : (1u << 24);
-        sq += (uint64_t)a * a;
-      }
-      sumsq = wave_sum_u64(sq);
-    }
+    const float ss = sum_sq_f32<G::E>(v);
+    nrm2 = norm2_upper(ss);
+    if (check) below = norm_below<G::E>(v, ss, limit);
   } else {
 #pragma unroll
     for (int e = 0; e < G::E; ++e) v[e] = (int32_t)src[G::j_p1(lane, e)];
@@ -226,7 +305,6 @@ __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict
 //                     shapes), every distinct operand ("slot") is transformed ONCE per proof into a workspace in HBM,
 //                     and the rows only multiply-accumulate the stored transforms; rows that need more primes than
 //                     were stored fall back to in-wave transforms for the missing primes, so results stay exact.
-//   split_kernel      experiment (RZK_SPLIT=1): one prime per 16-bit key half for operands of small 1-norm.
 // =============================================================================================
 #ifndef RZK_ROW_MIN_WAVES
 #define RZK_ROW_MIN_WAVES 1   // minimum waves per SIMD the row kernels are compiled for (register budget)
@@ -237,11 +315,19 @@ __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict
 
 template <int LOGN>
 __device__ __forceinline__ void load_pairs(int32_t* v, const int64_t* __restrict__ src, int lane, uint32_t qhalf,
-                                           uint32_t& bad, uint32_t& mx) {
+                                           uint32_t& bad, uint32_t& mx, bool trusted) {
   using S = ShiftGeo<LOGN>;
   const longlong2* __restrict__ p = reinterpret_cast<const longlong2*>(src);
+  if (trusted) {
 #pragma unroll
-  for (int g = 0; g < S::G; ++g) canon_pair(p[g * 64 + lane], qhalf, bad, mx, v[2 * g], v[2 * g + 1]);   // coefficients g*128 + 2*lane, +1
+    for (int g = 0; g < S::G; ++g) {
+      const longlong2 t = p[g * 64 + lane];
+      v[2 * g] = (int32_t)t.x, v[2 * g + 1] = (int32_t)t.y;
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < S::G; ++g) canon_pair(p[g * 64 + lane], qhalf, bad, mx, v[2 * g], v[2 * g + 1]);   // coefficients g*128 + 2*lane, +1
+  }
 }
 
 #ifndef RZK_SHIFT_H
@@ -277,7 +363,7 @@ __device__ __forceinline__ void shift_scan(int64_t* acc, const int32_t* a, int l
 // it also proves that v is canonical (canon_lo) and returns max |v| over the lane's coefficients.
 template <int LOGN, bool PAIR>
 __device__ __forceinline__ void shift_fill_from(const int64_t* __restrict__ pv, int lane, int32_t* ext, int part,
-                                                bool measure, uint32_t qhalf, uint32_t& bad, uint32_t& mx,
+                                                bool measure, bool canon, uint32_t qhalf, uint32_t& bad, uint32_t& mx,
                                                 uint32_t& maxabs) {
   using S = ShiftGeo<LOGN, PAIR>;
   constexpr int H = S::E / 2;               // registers per half; off(h*H + i) = off(i) + h * 32 * E in both layouts
@@ -290,7 +376,7 @@ __device__ __forceinline__ void shift_fill_from(const int64_t* __restrict__ pv, 
 #pragma unroll
       for (int g = 0; g < H / 2; ++g) {
         const longlong2 t = p[g * 64 + lane];   // coefficients (h*H/2 + g)*128 + 2*lane, +1
-        if (measure) {
+        if (canon) {
           canon_pair(t, qhalf, bad, mx, vh[2 * g], vh[2 * g + 1]);
         } else {
           vh[2 * g] = (int32_t)t.x;
@@ -302,13 +388,14 @@ __device__ __forceinline__ void shift_fill_from(const int64_t* __restrict__ pv, 
 #pragma unroll
       for (int i = 0; i < H; ++i) {
         const int64_t c = p[i * 64 + lane];
-        vh[i] = measure ? canon_lo_mx(c, qhalf, bad, mx) : (int32_t)c;
+        vh[i] = canon ? canon_lo_mx(c, qhalf, bad, mx) : (int32_t)c;
       }
     }
     if (measure) {
 #pragma unroll
       for (int i = 0; i < H; ++i) {
-        const uint32_t vv = (uint32_t)(vh[i] < 0 ? -vh[i] : vh[i]);
+        const uint32_t uu = (uint32_t)vh[i];
+        const uint32_t vv = vh[i] < 0 ? 0u - uu : uu;
         maxabs = vv > maxabs ? vv : maxabs;
       }
     }
@@ -332,7 +419,7 @@ __device__ __forceinline__ void shift_fill_from(const int64_t* __restrict__ pv, 
 template <int LOGN, bool PAIR, bool TO_MEM>
 __device__ __forceinline__ void shift_product(uint32_t* res, bool fresh, bool minus, const int32_t* a,
                                               const int64_t* __restrict__ pv, int lane, int32_t* ext,
-                                              const DevTables& T, bool& fault) {
+                                              const DevTables& T, bool& fault, bool trusted) {
   using S = ShiftGeo<LOGN, PAIR>;
   constexpr int E = S::E;
   constexpr int HW = TO_MEM ? RZK_SHIFT_H_MEM : RZK_SHIFT_H;   // (the in-kernel rotation terms run with nothing else live)
@@ -342,19 +429,22 @@ __device__ __forceinline__ void shift_product(uint32_t* res, bool fresh, bool mi
   // optimistic first fill with the whole values; it also measures v
   uint32_t vbad = 0, vmx = 0, maxv = 0;
   wave_sync();   // earlier reads of the image are done before it is overwritten
-  shift_fill_from<LOGN, PAIR>(pv, lane, ext, SHIFT_WHOLE, true, qhalf, vbad, vmx, maxv);
-  fault = fault || canon_fail(vbad, vmx, qhalf);
+  shift_fill_from<LOGN, PAIR>(pv, lane, ext, SHIFT_WHOLE, true, !trusted, qhalf, vbad, vmx, maxv);
+  if (!trusted) fault = fault || canon_fail(vbad, vmx, qhalf);
   uint64_t suma = 0;
 #pragma unroll
-  for (int i = 0; i < E; ++i) suma += (uint32_t)(a[i] < 0 ? -a[i] : a[i]);
-  const double bound = (double)wave_sum_u64(suma) * (double)wave_max_u32(maxv);   // |exact product|_inf
+  for (int i = 0; i < E; ++i) {
+    const uint32_t ua = (uint32_t)a[i];
+    suma += a[i] < 0 ? 0u - ua : ua;
+  }
+  const double bound = (double)wave_sum_u56(suma) * (double)wave_max_u32(maxv);   // |exact product|_inf (E * 2^31 < 2^56 per lane)
   const int npass = __builtin_amdgcn_readfirstlane(bound < 4.0e18 ? 1 : 2);        // 4.0e18 < 2^62
 #pragma unroll 1
   for (int pass = 0; pass < npass; ++pass) {
     if (npass == 2) {   // (never for a sparse +-1 challenge) the image is rebuilt from 16-bit halves
       uint32_t u0 = 0, u1 = 0, u2 = 0;
       wave_sync();
-      shift_fill_from<LOGN, PAIR>(pv, lane, ext, pass == 0 ? SHIFT_LOW16 : SHIFT_HIGH16, false, qhalf, u0, u1, u2);
+      shift_fill_from<LOGN, PAIR>(pv, lane, ext, pass == 0 ? SHIFT_LOW16 : SHIFT_HIGH16, false, false, qhalf, u0, u1, u2);
     }
     wave_sync();
 #pragma unroll 1
@@ -389,7 +479,7 @@ template <int LOGN, bool HAS_VEC, bool OPQ = false>
 __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const Operands& ops, uint32_t b,
                                             uint32_t bo, int lane, uint32_t* lds, const uint32_t* __restrict__ twf,
                                             const PrimeConsts& pc, int pi, const uint32_t* __restrict__ key_ntt,
-                                            const double* __restrict__ key_inf, bool first, double& bound,
+                                            const double* __restrict__ key_l2, bool first, float& bound,
                                             uint8_t* __restrict__ flags, uint32_t qhalf) {
   using G = Geo<LOGN>;
   constexpr int E = G::E;
@@ -398,26 +488,23 @@ __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const 
   int ln = lane;
   RZK_OPAQUE(ln);
   uint32_t x[E];
-  double l1b = 0, infb = 0;
-  uint64_t sumsq = 0;
-  bool fault = false;
+  float nb = 0.f;
+  bool below = true, fault = false;
   const bool chk = first && (tm.kind & (TERM_CHECK | TERM_CHECK2));
-  load_lift<LOGN>(x, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), ln, pc, first, l1b, infb, chk, sumsq, qhalf, fault);
-  if (chk && sumsq >= ops.norm_limit && lane == 0) fail_check(flags + bo, ops.pad != 0, (tm.kind & TERM_CHECK2) != 0);
+  const bool trusted = ops.trusted != 0;
+  load_lift<LOGN>(x, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), ln, pc, first, nb, chk, ops.norm_limit, below, qhalf, trusted, fault);
+  if (chk && !below && lane == 0) fail_check(flags + bo, ops.pad != 0, (tm.kind & TERM_CHECK2) != 0);
   wave_fwd<LOGN>(x, ln, lds, twf, pc);
   if (HAS_VEC && (tm.kind & TERM_KIND_MASK) == TERM_VEC) {
     // product of two per-proof polynomials: fold N^-1 and the Montgomery factor into one of them
     uint32_t xb[E];
 #pragma unroll
     for (int c = 0; c < E; ++c) xb[c] = csub(mont_lazy(x[c], pc.ninv_r2, pc.p, pc.npinv), pc.p);
-    double l1a = 0, infa = 0;
-    uint64_t unused_sq = 0;
-    load_lift<LOGN>(x, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), ln, pc, first, l1a, infa, false, unused_sq, qhalf, fault);
+    float na = 0.f;
+    bool unused_below = true;
+    load_lift<LOGN>(x, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), ln, pc, first, na, false, 0, unused_below, qhalf, trusted, fault);
     wave_fwd<LOGN>(x, ln, lds, twf, pc);
-    if (first) {
-      const double u = l1a * infb, v = infa * l1b;
-      bound += u < v ? u : v;
-    }
+    if (first) bound = bound_fma(na, nb, bound);   // |a (*) b|_inf <= |a|_2 |b|_2
     if (tm.sign >= 0) {
 #pragma unroll
       for (int c = 0; c < E; ++c) acc[c] = mac_add(acc[c], x[c], xb[c], pc);
@@ -426,7 +513,7 @@ __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const 
       for (int c = 0; c < E; ++c) acc[c] = mac_sub(acc[c], x[c], xb[c], pc);
     }
   } else {
-    if (first) bound += key_inf[tm.a_off] * l1b;
+    if (first) bound = bound_fma((float)key_l2[tm.a_off], nb, bound);
     const uint4* __restrict__ kp = reinterpret_cast<const uint4*>(key_ntt + ((size_t)tm.a_off * kKeyImages + pi) * N);
     if (tm.sign >= 0) {
 #pragma unroll
@@ -488,6 +575,74 @@ __device__ __forceinline__ void inverse_and_fold(int pi, int np, uint32_t* acc, 
   }
 }
 
+// Checked additions (ADD_CHECK / ADD_CHECK2: the host marks them only among the first four additions of a row): the
+// fused norm predicate sum c^2 < limit of the polynomial an addition loads.  The epilogues accumulate the float sum
+// of squares per marked addition while they load it; the verdict is taken here, exactly (see "norms" above: float
+// total outside the rounding band of the limit, otherwise the polynomial is re-read and summed in integers).
+template <int LOGN>
+__device__ __forceinline__ void checked_add_verdicts(const Program* __restrict__ prog, const Row row, const Operands& ops,
+                                                     uint32_t b, uint32_t bo, int lane, const float* add_ss,
+                                                     uint8_t* __restrict__ flags) {
+  using G = Geo<LOGN>;
+#pragma unroll 1
+  for (uint32_t a = 0; a < row.nadds && a < 4; ++a) {
+    const AddTerm ad = table_load(&prog->adds[row.add0 + a]);
+    if (!(ad.op & (ADD_CHECK | ADD_CHECK2))) continue;
+    float part = 0.f;
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) part = (sl == (int)a) ? add_ss[sl] : part;
+    const double sfl = (double)wave_sum_f32(part), lim = (double)ops.norm_limit;
+    bool below;
+    if (sfl * (1.0 + 2.0 * (double)kNormSlack) < lim) {
+      below = true;
+    } else if (sfl * (1.0 - 2.0 * (double)kNormSlack) >= lim) {
+      below = false;
+    } else {
+      const int64_t* __restrict__ src = operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, G::N);
+      int32_t v[G::E];
+#pragma unroll
+      for (int e = 0; e < G::E; ++e) v[e] = (int32_t)src[G::j_p1(lane, e)];
+      below = sum_sq_exact<G::E>(v) < ops.norm_limit;
+    }
+    if (!below && lane == 0) fail_check(flags + bo, ops.pad != 0, (ad.op & ADD_CHECK2) != 0);
+  }
+}
+
+// One chunk of one plain addition: u[i] +/-= operand coefficient (j_p1(lane, e0 + i)) in 32-bit arithmetic mod q;
+// canonical test unless trusted; float sum of squares into add_ss[slot] for checked additions.
+template <int LOGN, int CH>
+__device__ __forceinline__ void add_chunk(uint32_t* u, const AddTerm ad, uint32_t a, const int64_t* __restrict__ src, int lane,
+                                          int e0, uint32_t q, uint32_t qhalf, bool trusted, uint32_t& in_bad, uint32_t& in_mx,
+                                          float* add_ss) {
+  using G = Geo<LOGN>;
+  int32_t av[CH];
+  if (trusted) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) av[i] = (int32_t)src[G::j_p1(lane, e0 + i)];
+  } else {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) av[i] = canon_lo_mx(src[G::j_p1(lane, e0 + i)], qhalf, in_bad, in_mx);
+  }
+  if (ad.op & (ADD_CHECK | ADD_CHECK2)) {
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const float f = (float)av[i];
+      sq = __builtin_fmaf(f, f, sq);
+    }
+    const uint32_t slot = a < 4 ? a : 3;
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) add_ss[sl] += (sl == (int)slot) ? sq : 0.f;
+  }
+  if (ad.sign >= 0) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) u[i] = addq(u[i], zq_from_centered(av[i], q), q);
+  } else {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) u[i] = subq(u[i], zq_from_centered(av[i], q), q);
+  }
+}
+
 // plain additions in 32-bit arithmetic mod q, then centre and store / zero test; RZK_EPI_CHUNK coefficients
 // per lane at a time.  Checked additions also evaluate the fused norm predicate.
 template <int LOGN>
@@ -501,8 +656,9 @@ __device__ __forceinline__ void row_epilogue(const Program* __restrict__ prog, c
   int nz = 0;
   constexpr int CH = RZK_EPI_CHUNK < E ? RZK_EPI_CHUNK : E;
   const uint32_t q = T.crt.q;
-  uint64_t add_sq[4] = {0, 0, 0, 0};   // per-lane partial sums of squares of checked additions (slot = add index)
-  uint32_t in_bad = 0, in_mx = 0;      // canonical-input test of the additions' coefficients
+  const bool trusted = ops.trusted != 0;
+  float add_ss[4] = {0.f, 0.f, 0.f, 0.f};   // per-lane partial sums of squares of checked additions (slot = add index)
+  uint32_t in_bad = 0, in_mx = 0;           // canonical-input test of the additions' coefficients
 #pragma unroll
   for (int e0 = 0; e0 < E; e0 += CH) {
     uint32_t u[CH];
@@ -519,28 +675,9 @@ __device__ __forceinline__ void row_epilogue(const Program* __restrict__ prog, c
     }
 #pragma unroll 1
     for (uint32_t a = 0; a < row.nadds; ++a) {
-      const AddTerm ad = prog->adds[row.add0 + a];
-      const int64_t* __restrict__ src = operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, N);
-      int32_t av[CH];
-#pragma unroll
-      for (int i = 0; i < CH; ++i) av[i] = canon_lo_mx(src[G::j_p1(lane, e0 + i)], T.crt.qhalf, in_bad, in_mx);
-      if (ad.op & (ADD_CHECK | ADD_CHECK2)) {
-        uint64_t sq = 0;
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-          uint32_t aa = (uint32_t)(av[i] < 0 ? -av[i] : av[i]);
-          aa = aa < (1u << 24) ? aa : (1u << 24);
-          sq += (uint64_t)aa * aa;
-        }
-        add_sq[a < 4 ? a : 3] += sq;
-      }
-      if (ad.sign >= 0) {
-#pragma unroll
-        for (int i = 0; i < CH; ++i) u[i] = addq(u[i], zq_from_centered(av[i], q), q);
-      } else {
-#pragma unroll
-        for (int i = 0; i < CH; ++i) u[i] = subq(u[i], zq_from_centered(av[i], q), q);
-      }
+      const AddTerm ad = table_load(&prog->adds[row.add0 + a]);
+      add_chunk<LOGN, CH>(u, ad, a, operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, N), lane, e0, q, T.crt.qhalf, trusted,
+                          in_bad, in_mx, add_ss);
     }
     if (row.mode == MODE_STORE) {
       int64_t* __restrict__ dst = const_cast<int64_t*>(operand_ptr(ops, row.out_op, row.out_off, b, bo, N));
@@ -554,26 +691,13 @@ __device__ __forceinline__ void row_epilogue(const Program* __restrict__ prog, c
   if (row.mode != MODE_STORE) {
     if (__any(nz) && lane == 0) flags[bo] = 0;
   }
-  if (row.nadds && canon_fail(in_bad, in_mx, T.crt.qhalf)) input_fault(ops, flags, bo, lane);
-  if (ops.norm_limit) {
-    // checked additions: the host marks them only among the first four additions of a row
-#pragma unroll 1
-    for (uint32_t a = 0; a < row.nadds && a < 4; ++a) {
-      const uint8_t aop = prog->adds[row.add0 + a].op;
-      if (aop & (ADD_CHECK | ADD_CHECK2)) {
-        uint64_t tot = 0;
-#pragma unroll
-        for (int sl = 0; sl < 4; ++sl) tot = (sl == (int)a) ? add_sq[sl] : tot;
-        tot = wave_sum_u64(tot);
-        if (tot >= ops.norm_limit && lane == 0) fail_check(flags + bo, ops.pad != 0, (aop & ADD_CHECK2) != 0);
-      }
-    }
-  }
+  if (row.nadds && !trusted && canon_fail(in_bad, in_mx, T.crt.qhalf)) input_fault(ops, flags, bo, lane);
+  if (ops.norm_limit) checked_add_verdicts<LOGN>(prog, row, ops, b, bo, lane, add_ss, flags);
 }
 
-__device__ __forceinline__ int primes_for(double bound, const DevTables& T) {
+__device__ __forceinline__ int primes_for(float fbound, const DevTables& T) {
   // |exact result| <= bound: the smallest prime count whose range covers it
-  bound *= 1.0 + 1e-9;   // the double products are rounded; stay on the safe side
+  const double bound = (double)fbound * (1.0 + 0x1p-12);   // float sums of up to kMaxTerms rounded products: stay on the safe side
   const int np = bound <= T.cap[1] ? 1 : (bound <= T.cap[2] ? 2 : 3);
   return __builtin_amdgcn_readfirstlane(np);
 }
@@ -637,28 +761,6 @@ __device__ __forceinline__ void set_progress_priority(uint32_t done, uint32_t to
   (void)done, (void)total;
 #endif
 }
-// When a workgroup fills the CU (16 waves: the four waves of every SIMD are workgroup mates) the waves of a SIMD rank
-// themselves exactly: each publishes the work it has left in an LDS word and takes the priority of its rank (most
-// work left = most urgent), so all four reach the end of the launch together.
-struct FairTable {
-  uint32_t left[4][4];   // [SIMD][slot]: steps the wave still has to do (0: finished / no wave)
-  uint32_t count[4];     // slots handed out per SIMD
-};
-__device__ __forceinline__ void set_rank_priority(FairTable* ft, uint32_t simd, uint32_t slot, uint32_t left, int lane) {
-#if RZK_FAIR_PRIO
-  if (lane == 0) __hip_atomic_store(&ft->left[simd][slot], left, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  uint32_t rank = 0;
-#pragma unroll
-  for (uint32_t m = 0; m < 4; ++m) {
-    const uint32_t o = __hip_atomic_load(&ft->left[simd][m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    rank += (m != slot) && (o > left || (o == left && m < slot));
-  }
-  set_priority_level(__builtin_amdgcn_readfirstlane(rank));
-#else
-  (void)ft, (void)simd, (void)slot, (void)left, (void)lane;
-#endif
-}
-
 // x (transform, phase-3 register order) times `mul` (a resident key entry or a second transform, in registers), into
 // row A's accumulator.  init: nothing accumulated yet; to_regs: the unit's last item -> the sum replaces x, else -> P
 template <int LOGN, bool to_regs, bool MINUS>
@@ -799,6 +901,7 @@ __device__ __forceinline__ void finish_row(uint32_t* u, const Program* __restric
   constexpr int E = G::E;
   constexpr int N = G::N;
   const uint32_t q = T.crt.q, qhalf = T.crt.qhalf;
+  const bool trusted = ops.trusted != 0;
   if (st_sh) {
 #pragma unroll
     for (int e = 0; e < E; ++e) u[e] = addq(u[e], st_sh[G::j_p1(lane, e)], q);
@@ -806,7 +909,7 @@ __device__ __forceinline__ void finish_row(uint32_t* u, const Program* __restric
   // An addition is loaded with up to 16 of a lane's coefficients in flight (a row's wall time is dominated by how
   // often it waits for HBM; 16 sixty-four-bit values are what the register budget of 4 waves per SIMD leaves room for).
   constexpr int CH = E < CHMAX ? E : CHMAX;
-  uint64_t add_sq[4] = {0, 0, 0, 0};
+  float add_ss[4] = {0.f, 0.f, 0.f, 0.f};
   uint32_t in_bad = 0, in_mx = 0;
   int nz = 0;
 #pragma unroll
@@ -814,29 +917,8 @@ __device__ __forceinline__ void finish_row(uint32_t* u, const Program* __restric
 #pragma unroll 1
     for (uint32_t a = 0; a < row.nadds; ++a) {
       const AddTerm ad = table_load(&prog->adds[row.add0 + a]);
-      const int64_t* __restrict__ src = operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, N);
-      int32_t av[CH];
-#pragma unroll
-      for (int i = 0; i < CH; ++i) av[i] = canon_lo_mx(src[G::j_p1(lane, e0 + i)], qhalf, in_bad, in_mx);
-      if (ad.op & (ADD_CHECK | ADD_CHECK2)) {
-        uint64_t sq = 0;
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-          uint32_t aa = (uint32_t)(av[i] < 0 ? -av[i] : av[i]);
-          aa = aa < (1u << 24) ? aa : (1u << 24);
-          sq += (uint64_t)aa * aa;
-        }
-        const uint32_t slot = a < 4 ? a : 3;
-#pragma unroll
-        for (int sl = 0; sl < 4; ++sl) add_sq[sl] += (sl == (int)slot) ? sq : 0ull;
-      }
-      if (ad.sign >= 0) {
-#pragma unroll
-        for (int i = 0; i < CH; ++i) u[e0 + i] = addq(u[e0 + i], zq_from_centered(av[i], q), q);
-      } else {
-#pragma unroll
-        for (int i = 0; i < CH; ++i) u[e0 + i] = subq(u[e0 + i], zq_from_centered(av[i], q), q);
-      }
+      add_chunk<LOGN, CH>(u + e0, ad, a, operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, N), lane, e0, q, qhalf, trusted,
+                          in_bad, in_mx, add_ss);
     }
     if (row.mode == MODE_STORE) {
       int64_t* __restrict__ dst = const_cast<int64_t*>(operand_ptr(ops, row.out_op, row.out_off, b, bo, N));
@@ -850,40 +932,24 @@ __device__ __forceinline__ void finish_row(uint32_t* u, const Program* __restric
   if (row.mode != MODE_STORE) {
     if (__any(nz) && lane == 0) flags[bo] = 0;
   }
-  if (row.nadds && canon_fail(in_bad, in_mx, qhalf)) input_fault(ops, flags, bo, lane);
-  if (ops.norm_limit) {
-    // checked additions: the host marks them only among the first four additions of a row
-#pragma unroll 1
-    for (uint32_t a = 0; a < row.nadds && a < 4; ++a) {
-      const uint8_t aop = table_load(&prog->adds[row.add0 + a]).op;
-      if (aop & (ADD_CHECK | ADD_CHECK2)) {
-        uint64_t tot = 0;
-#pragma unroll
-        for (int sl = 0; sl < 4; ++sl) tot = (sl == (int)a) ? add_sq[sl] : tot;
-        tot = wave_sum_u64(tot);
-        if (tot >= ops.norm_limit && lane == 0) fail_check(flags + bo, ops.pad != 0, (aop & ADD_CHECK2) != 0);
-      }
-    }
-  }
+  if (row.nadds && !trusted && canon_fail(in_bad, in_mx, qhalf)) input_fault(ops, flags, bo, lane);
+  if (ops.norm_limit) checked_add_verdicts<LOGN>(prog, row, ops, b, bo, lane, add_ss, flags);
 }
 
-// Wavefronts per workgroup: 16 (the whole CU: exact fairness among SIMD mates, see set_rank_priority) up to N = 1024;
-// 4 at N = 2048, where 16 slabs do not fit the CU's LDS.
-#ifndef RZK_UNIT_WPB
-#define RZK_UNIT_WPB 4   // (16-wave workgroups with rank priorities measured slower for the verify rows: 90 vs 81 us)
-#endif
+// Wavefronts per workgroup: 4 independent waves (16-wave workgroups whose SIMD mates ranked each other through an LDS
+// table for exact fairness measured slower in round 2 — verify rows 90 vs 81 us — and were removed).
 template <int LOGN>
 struct UnitCfg {
-  static constexpr int WPB = LOGN <= 10 ? RZK_UNIT_WPB : 4;
+  static constexpr int WPB = 4;
 };
 
 template <int LOGN, bool HAS_VEC, bool HAS_SHIFT>
 __global__ void __launch_bounds__(64 * UnitCfg<LOGN>::WPB, (LOGN <= 10 && HAS_VEC ? 4 : 1))   // vector x vector variants: hold the 4 waves per SIMD the LDS allows
 unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp, const Operands ops,
-            const uint32_t* __restrict__ key_ntt, const double* __restrict__ key_inf, const DevTables* __restrict__ Tp,
+            const uint32_t* __restrict__ key_ntt, const double* __restrict__ key_l2, const DevTables* __restrict__ Tp,
             const uint32_t* __restrict__ tw_all, uint32_t* __restrict__ scratch, uint8_t* __restrict__ flags,
             const uint32_t ntasks, const uint32_t units_per_task, const uint32_t tasks_per_entry,
-            const uint32_t work_per_task, const uint8_t* __restrict__ done) {
+            const uint32_t work_per_task) {
   using G = Geo<LOGN>;
   constexpr int E = G::E;
   constexpr int N = G::N;
@@ -892,21 +958,8 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
   const int lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   constexpr int WPB = UnitCfg<LOGN>::WPB;
-  constexpr bool RANKED = WPB == 16;
   uint32_t* lds = smem + wave * (G::LDS_WORDS + N);             // transposition slab, then P
   uint4* P4 = reinterpret_cast<uint4*>(lds + G::LDS_WORDS);     // G::LDS_WORDS * 4 is a multiple of 16 bytes
-  FairTable* ft = reinterpret_cast<FairTable*>(smem + WPB * (G::LDS_WORDS + N));
-  uint32_t my_simd = 0, my_slot = 0;
-  if (RANKED) {
-    if (threadIdx.x < sizeof(FairTable) / 4) reinterpret_cast<uint32_t*>(ft)[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t hwid;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-    my_simd = (hwid >> 4) & 3u;
-    uint32_t sl = 0;
-    if (lane == 0) sl = __hip_atomic_fetch_add(&ft->count[my_simd], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    my_slot = __builtin_amdgcn_readfirstlane(sl) & 3u;
-  }
   // per-wave global scratch: Garner words [row A | B][word A | B][N], then the sum of row A's rotation terms
   uint32_t* st = scratch + ((size_t)blockIdx.x * WPB + wave) * (size_t)(kScratchLines * N + 16);
   uint32_t* st_sh = st + 4 * N;
@@ -917,6 +970,7 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
 #endif
   const DevTables& T = *Tp;
   const uint32_t qhalf = T.crt.qhalf;
+  const bool trusted = ops.trusted != 0;
   const uint32_t nunits = wp->nunits;
 
   // progress of this wave through its share of the launch, in transforms (work_per_task: the host's estimate)
@@ -928,11 +982,10 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
   const uint32_t my_tasks = first_task < ntasks ? (ntasks - first_task + gridDim.x * WPB - 1) / (gridDim.x * WPB) : 0;
   const uint32_t work_total = my_tasks * work_per_task;
   uint32_t work_done = 0;
-#define RZK_STEP_PRIORITY()                                                                                  \
-  do {                                                                                                       \
-    if (RANKED) set_rank_priority(ft, my_simd, my_slot, work_total > work_done ? work_total - work_done : 1u, lane); \
-    else set_progress_priority(work_done, work_total);                                                        \
-    ++work_done;                                                                                             \
+#define RZK_STEP_PRIORITY()                             \
+  do {                                                  \
+    set_progress_priority(work_done, work_total);       \
+    ++work_done;                                        \
   } while (0)
 
   for (uint32_t task = first_task; task < ntasks; task += gridDim.x * WPB) {
@@ -950,8 +1003,7 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
       const Unit un = table_load(&wp->units[ui]);
       const Row rowA = table_load(&prog->rows[un.rowA]);
       const bool pair = un.rowB != kNoRow;
-      if (done && (un.nitems & kUnitSplit) && done[(size_t)b * nunits + ui]) continue;   // finished by split_kernel
-      const uint32_t un_items = un.nitems & kUnitItemsMask;   // (the kUnitSplit flag rides in the same field)
+      const uint32_t un_items = un.nitems;
       const bool null_unit = un_items == 0;   // no products: additions / rotation terms only
       const bool has_shift = HAS_SHIFT && rowA.nshift > 0;
       if (has_shift) {
@@ -964,12 +1016,17 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
           const Term tm = table_load(&prog->terms[rowA.term0 + rowA.nterms + t]);
           const int64_t* __restrict__ pa = operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N);
           int32_t a[E];
-          uint32_t abad = 0, amx = 0;
+          if (trusted) {
 #pragma unroll
-          for (int e = 0; e < E; ++e) a[e] = canon_lo_mx(pa[G::j_p1(lane, e)], qhalf, abad, amx);
-          fault = fault || canon_fail(abad, amx, qhalf);
+            for (int e = 0; e < E; ++e) a[e] = (int32_t)pa[G::j_p1(lane, e)];
+          } else {
+            uint32_t abad = 0, amx = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) a[e] = canon_lo_mx(pa[G::j_p1(lane, e)], qhalf, abad, amx);
+            fault = fault || canon_fail(abad, amx, qhalf);
+          }
           shift_product<LOGN, false, true>(st_sh, t == 0, tm.sign < 0, a, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane,
-                                           reinterpret_cast<int32_t*>(lds), T, fault);
+                                           reinterpret_cast<int32_t*>(lds), T, fault, trusted);
         }
         if (fault) input_fault(ops, flags, bo, lane);
         wave_sync();   // the image is dead: slab and P may be overwritten
@@ -977,7 +1034,7 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
       }
       int np = null_unit ? 1 : kMaxPrimes;
       const uint32_t nit = null_unit ? 1u : un_items;
-      double boundA = 0.0, boundB = 0.0;
+      float boundA = 0.f, boundB = 0.f;
 #pragma unroll 1
       for (int pi = 0; pi < np; ++pi) {
         const PrimeConsts pc = T.pc[pi];
@@ -997,16 +1054,16 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
           if (!null_unit) {
             const Item im = table_load(&wp->items[un.item0 + it]);
             uint32_t x[E];      // the current transform
-            double l1b = 0, infb = 0;
-            uint64_t sumsq = 0;
+            float nb = 0.f;
+            bool below = true;
             const bool chk = first && (im.flags & (TERM_CHECK | TERM_CHECK2));
             {
               RZK_T0();
-              load_lift<LOGN>(x, operand_ptr(ops, im.b_op, im.b_off, b, bo, N), ln, pc, first, l1b, infb, chk, sumsq, qhalf, fault);
+              load_lift<LOGN>(x, operand_ptr(ops, im.b_op, im.b_off, b, bo, N), ln, pc, first, nb, chk, ops.norm_limit, below, qhalf,
+                              trusted, fault);
               RZK_T1(t_load);
             }
-            if (chk && sumsq >= ops.norm_limit && lane == 0)
-              fail_check(flags + bo, ops.pad != 0, (im.flags & TERM_CHECK2) != 0);
+            if (chk && !below && lane == 0) fail_check(flags + bo, ops.pad != 0, (im.flags & TERM_CHECK2) != 0);
             const bool vec = HAS_VEC && im.kind == ITEM_VEC;
             // the resident key entry of row A's product is requested before the transform, which hides its latency
             // (N <= 1024; at N = 2048 the registers are not there and the entry is loaded after the transform)
@@ -1036,18 +1093,15 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
             if (vec) {
 #pragma unroll
               for (int c = 0; c < E; ++c) xb[c] = csub(mont_lazy(x[c], pc.ninv_r2, pc.p, pc.npinv), pc.p);
-              double l1a = 0, infa = 0;
-              uint64_t unused_sq = 0;
-              load_lift<LOGN>(x, operand_ptr(ops, im.a_op, im.a_off, b, bo, N), ln, pc, first, l1a, infa, false, unused_sq,
-                              qhalf, fault);
+              float na = 0.f;
+              bool unused_below = true;
+              load_lift<LOGN>(x, operand_ptr(ops, im.a_op, im.a_off, b, bo, N), ln, pc, first, na, false, 0, unused_below, qhalf,
+                              trusted, fault);
               wave_fwd<LOGN>(x, ln, lds, twf, pc);
-              if (first) {
-                const double p0 = l1a * infb, p1 = infa * l1b;
-                boundA += p0 < p1 ? p0 : p1;
-              }
+              if (first) boundA = bound_fma(na, nb, boundA);
             } else if (first) {
-              if (im.keyA != kNoKey) boundA += key_inf[im.keyA] * l1b;
-              if (pair && im.keyB != kNoKey) boundB += key_inf[im.keyB] * l1b;
+              if (im.keyA != kNoKey) boundA = bound_fma((float)key_l2[im.keyA], nb, boundA);
+              if (pair && im.keyB != kNoKey) boundB = bound_fma((float)key_l2[im.keyB], nb, boundB);
             }
             const bool feedsA = vec || im.keyA != kNoKey;
             if (!last) {
@@ -1116,7 +1170,6 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
     }
   }
 #undef RZK_STEP_PRIORITY
-  if (RANKED && lane == 0) __hip_atomic_store(&ft->left[my_simd][my_slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #if RZK_STAMPS
   if (lane == 0) {
     const uint64_t stamp1 = __builtin_amdgcn_s_memrealtime();
@@ -1146,7 +1199,7 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
 template <int LOGN, bool HAS_SHIFT>
 __global__ void __launch_bounds__(256, (LOGN <= 10 ? 4 : 1))   // N <= 1024: hold the 4 waves per SIMD the LDS allows
 row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t* __restrict__ key_ntt,
-           const double* __restrict__ key_inf, const DevTables* __restrict__ Tp, const uint32_t* __restrict__ tw_all,
+           const double* __restrict__ key_l2, const DevTables* __restrict__ Tp, const uint32_t* __restrict__ tw_all,
            uint32_t* __restrict__ scratch, uint8_t* __restrict__ flags, const uint32_t ntasks) {
   using G = Geo<LOGN>;
   constexpr int E = G::E;
@@ -1164,6 +1217,7 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
   uint32_t* st_sh = st + 4 * N;     // sum of the row's rotation terms mod q
   const DevTables& T = *Tp;
   const uint32_t qhalf = T.crt.qhalf;
+  const bool trusted = ops.trusted != 0;
   const uint32_t nrows = prog->nrows;
 
   for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
@@ -1179,12 +1233,17 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
         const Term tm = table_load(&prog->terms[row.term0 + row.nterms + t]);
         const int64_t* __restrict__ pa = operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N);
         int32_t a[E];
-        uint32_t abad = 0, amx = 0;
+        if (trusted) {
 #pragma unroll
-        for (int e = 0; e < E; ++e) a[e] = canon_lo_mx(pa[G::j_p1(lane, e)], qhalf, abad, amx);
-        fault = fault || canon_fail(abad, amx, qhalf);
+          for (int e = 0; e < E; ++e) a[e] = (int32_t)pa[G::j_p1(lane, e)];
+        } else {
+          uint32_t abad = 0, amx = 0;
+#pragma unroll
+          for (int e = 0; e < E; ++e) a[e] = canon_lo_mx(pa[G::j_p1(lane, e)], qhalf, abad, amx);
+          fault = fault || canon_fail(abad, amx, qhalf);
+        }
         shift_product<LOGN, false, true>(st_sh, t == 0, tm.sign < 0, a, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane,
-                                         reinterpret_cast<int32_t*>(lds), T, fault);
+                                         reinterpret_cast<int32_t*>(lds), T, fault, trusted);
       }
       if (fault) input_fault(ops, flags, bo, lane);
       wave_sync();   // the image is dead: the slab and the state words may be overwritten
@@ -1192,7 +1251,7 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
     const bool has_terms = row.nterms > 0;
     int np = kMaxPrimes;
     if (has_terms) {
-      double bound = 0.0;
+      float bound = 0.f;
 #pragma unroll 1
       for (int pi = 0; pi < np; ++pi) {
         const PrimeConsts pc = T.pc[pi];
@@ -1204,221 +1263,12 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
 #pragma unroll 1
         for (uint32_t t = 0; t < row.nterms; ++t)
           term_direct<LOGN, true, OPQ>(acc, table_load(&prog->terms[row.term0 + t]), ops, b, bo, lane, lds, twf, pc, pi, key_ntt,
-                                       key_inf, first, bound, flags, qhalf);
+                                       key_l2, first, bound, flags, qhalf);
         if (first) np = primes_for(bound, T);
         inverse_and_fold<LOGN, OPQ>(pi, np, acc, lane, lds, twf + kTableLen, pc, st_lds, st_glb, T);
       }
     }
     row_epilogue<LOGN>(prog, row, ops, b, bo, lane, has_terms, np, st_lds, T, flags, has_shift ? st_sh : nullptr);
-  }
-}
-
-// =============================================================================================
-// split_kernel: key products whose operands have a SMALL 1-norm — the ternary randomness r of every commitment
-// (commit.rs:98-107: c = [a1;a2].r + [0;x] is a third of all transforms of an Open cycle).  With the key entries
-// available as two 16-bit halves under prime 0 (rzk_core.h, kKeyImages), K (*) v fits ONE prime per half whenever
-// 2^15 * sum_j |v_j|_1 <= (p0 - 1) / 2, so a unit (one row, or a pair sharing its last operand) needs one forward
-// transform per operand instead of two, no second pass over the operands and no Garner step:
-//     value = lo + 2^16 hi  with  lo = sum Klo_j (*) v_j,  hi = sum Khi_j (*) v_j   (exact integers, |.| < 2^29).
-// The host launches this kernel for the units it EXPECTS to qualify (operands hinted small by the program builder);
-// whether a unit does is decided here, per proof, from the measured norms (so results are exact for every input).  A
-// unit that qualifies is finished here and marked in `done`; unit_kernel, launched next, skips marked units and
-// evaluates all others the general way.  Both operands are loaded once (raw low words in registers); the transforms
-// wait in P (first operand) and in the wave's scratch line (last operand) while the rows' half-sums are formed and
-// transformed back one after the other; the low half's integers wait in P during the high half's transform.
-// =============================================================================================
-template <int LOGN>
-__device__ __forceinline__ void load_raw(int32_t* v, const int64_t* __restrict__ src, int lane, uint32_t qhalf, double& l1,
-                                         bool want_sq, uint64_t& sumsq, bool& fault) {
-  using G = Geo<LOGN>;
-  uint32_t bad = 0;
-#pragma unroll
-  for (int e = 0; e < G::E; ++e) v[e] = canon_lo(src[G::j_p1(lane, e)], qhalf, bad);
-  uint64_t sum = 0;
-  uint32_t mx = 0;
-#pragma unroll
-  for (int e = 0; e < G::E; e += 2) {
-    const uint32_t a0 = (uint32_t)(v[e] < 0 ? -v[e] : v[e]);
-    const uint32_t a1 = (uint32_t)(v[e + 1] < 0 ? -v[e + 1] : v[e + 1]);
-    sum += (uint64_t)a0 + a1;
-    mx = a0 > mx ? a0 : mx;
-    mx = a1 > mx ? a1 : mx;
-  }
-  l1 = (double)wave_sum_u64(sum);
-  fault = fault || __any(bad != 0) || wave_max_u32(mx) > qhalf;
-  if (want_sq) {
-    uint64_t sq = 0;
-#pragma unroll
-    for (int e = 0; e < G::E; ++e) {
-      uint32_t a = (uint32_t)(v[e] < 0 ? -v[e] : v[e]);
-      a = a < (1u << 24) ? a : (1u << 24);
-      sq += (uint64_t)a * a;
-    }
-    sumsq = wave_sum_u64(sq);
-  }
-}
-
-// acc +/-= KEY image (global, 16-byte loads) (*) x, where x is a register array or, with FROM_MEM, a transform parked in
-// P (LDS) or in the wave's scratch line (key layout, 16-byte slots); four coefficients at a time, sign tested once
-template <int LOGN, bool FROM_MEM, bool MINUS, class XP>
-__device__ __forceinline__ void mac_key_signed(uint32_t* acc, const uint32_t* x, XP X4, const uint4* __restrict__ kp, int lane,
-                                               const PrimeConsts& pc) {
-  constexpr int E = Geo<LOGN>::E;
-#pragma unroll
-  for (int g = 0; g < E / 4; ++g) {
-    const uint4 kv = kp[g * 64 + lane];
-    const uint32_t ks[4] = {kv.x, kv.y, kv.z, kv.w};
-    uint32_t xs[4];
-    if (FROM_MEM) {
-      const uint4 xv = X4[g * 64 + lane];
-      xs[0] = xv.x, xs[1] = xv.y, xs[2] = xv.z, xs[3] = xv.w;
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) xs[i] = x[4 * g + i];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      acc[4 * g + i] = MINUS ? mac_sub(acc[4 * g + i], xs[i], ks[i], pc) : mac_add(acc[4 * g + i], xs[i], ks[i], pc);
-  }
-}
-template <int LOGN, bool FROM_MEM, class XP>
-__device__ __forceinline__ void mac_key(uint32_t* acc, const uint32_t* x, XP X4, const uint4* __restrict__ kp, bool minus, int lane,
-                                        const PrimeConsts& pc) {
-  if (minus) mac_key_signed<LOGN, FROM_MEM, true>(acc, x, X4, kp, lane, pc);
-  else mac_key_signed<LOGN, FROM_MEM, false>(acc, x, X4, kp, lane, pc);
-}
-
-template <int LOGN>
-__global__ void __launch_bounds__(256)
-split_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp, const Operands ops,
-             const uint32_t* __restrict__ key_ntt, const double* __restrict__ key_inf, const DevTables* __restrict__ Tp,
-             const uint32_t* __restrict__ tw_all, uint32_t* __restrict__ scratch, uint8_t* __restrict__ flags,
-             uint8_t* __restrict__ done, const uint32_t ntasks) {
-  using G = Geo<LOGN>;
-  constexpr int E = G::E;
-  constexpr int N = G::N;
-  constexpr bool OPQ = true;
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  uint32_t* lds = smem + wave * (G::LDS_WORDS + N);             // transposition slab, then P
-  uint4* P4 = reinterpret_cast<uint4*>(lds + G::LDS_WORDS);
-  uint32_t* st = scratch + ((size_t)blockIdx.x * 4 + wave) * (size_t)(kScratchLines * N + 16);
-  uint4* XL = reinterpret_cast<uint4*>(st + 5 * N);             // the last operand's transform
-  const DevTables& T = *Tp;
-  const uint32_t qhalf = T.crt.qhalf;
-  const uint32_t nunits = wp->nunits, nsplit = wp->nsplit;
-  const PrimeConsts pc = T.pc[0];
-  const uint32_t* __restrict__ twf = tw_all;
-
-  for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
-    const uint32_t b = task / nsplit;
-    const uint32_t ui = wp->split_units[task - b * nsplit];
-    const uint32_t bo = ops.group > 1 ? b / ops.group : b;
-    const Unit un = table_load(&wp->units[ui]);
-    const bool pair = un.rowB != kNoRow;
-    const uint32_t nit = un.nitems & kUnitItemsMask;   // 1 or 2
-    const Item i1 = table_load(&wp->items[un.item0 + nit - 1]);   // the last operand (feeds row A and a pair's row B)
-    const Item i0 = table_load(&wp->items[un.item0]);             // nit == 2: the first operand (row A only)
-    // ---- both operands: raw low words into registers (one pass over HBM), canonical test, norms, norm marks
-    int32_t v0[E], v1[E];
-    double l10 = 0.0, l11 = 0.0;
-    bool fault = false;
-    {
-      uint64_t sq = 0;
-      if (nit == 2) {
-        const bool chk = (i0.flags & (TERM_CHECK | TERM_CHECK2)) != 0;
-        load_raw<LOGN>(v0, operand_ptr(ops, i0.b_op, i0.b_off, b, bo, N), lane, qhalf, l10, chk, sq, fault);
-        if (chk && sq >= ops.norm_limit && lane == 0) fail_check(flags + bo, ops.pad != 0, (i0.flags & TERM_CHECK2) != 0);
-      } else {
-#pragma unroll
-        for (int e = 0; e < E; ++e) v0[e] = 0;
-      }
-      const bool chk1 = (i1.flags & (TERM_CHECK | TERM_CHECK2)) != 0;
-      load_raw<LOGN>(v1, operand_ptr(ops, i1.b_op, i1.b_off, b, bo, N), lane, qhalf, l11, chk1, sq, fault);
-      if (chk1 && sq >= ops.norm_limit && lane == 0) fail_check(flags + bo, ops.pad != 0, (i1.flags & TERM_CHECK2) != 0);
-    }
-    if (fault) input_fault(ops, flags, bo, lane);
-    const double boundA = (nit == 2 ? key_inf[i0.keyA] * l10 : 0.0) + (i1.keyA != kNoKey ? key_inf[i1.keyA] * l11 : 0.0);
-    const double boundB = pair ? key_inf[i1.keyB] * l11 : 0.0;
-    const int np = primes_for(boundA > boundB ? boundA : boundB, T);
-    const bool one = np == 1;                                               // one prime covers the whole product
-    const bool split = np == 2 && 32768.0 * (l10 + l11) <= T.cap[1];       // one prime per key half
-    const bool mine = __builtin_amdgcn_readfirstlane((one || split) ? 1 : 0) != 0;
-    if (lane == 0) done[(size_t)b * nunits + ui] = mine ? 1 : 0;
-    if (!mine) continue;   // unit_kernel evaluates this unit the general way
-
-    // ---- forward transforms under prime 0: X1 -> P, X2 -> scratch line
-#pragma unroll 1
-    for (uint32_t op = 2 - nit; op < 2; ++op) {
-      int ln = lane;
-      RZK_OPAQUE(ln);
-      uint32_t x[E];
-#pragma unroll
-      for (int e = 0; e < E; ++e) x[e] = lift(op ? v1[e] : v0[e], pc);
-      wave_fwd<LOGN>(x, ln, lds, twf, pc);
-      if (op) {
-#pragma unroll
-        for (int g = 0; g < E / 4; ++g) XL[g * 64 + ln] = make_uint4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
-      } else {
-#pragma unroll
-        for (int g = 0; g < E / 4; ++g) P4[g * 64 + ln] = make_uint4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
-      }
-    }
-    // ---- rows and their jobs: one inverse transform per key image (two in split mode)
-    const int njobs = one ? 1 : 2;
-#pragma unroll 1
-    for (uint32_t r = 0; r < (pair ? 2u : 1u); ++r) {
-      uint32_t keep[E];   // low half's integers (int32 bits)
-#pragma unroll 1
-      for (int j = 0; j < njobs; ++j) {
-        const int img = (one ? 0 : kImgLo) + j;
-        int li = lane;
-        RZK_OPAQUE(li);
-        uint32_t sacc[E];
-#pragma unroll
-        for (int c = 0; c < E; ++c) sacc[c] = 0;
-        if (r == 0 && nit == 2 && i0.keyA != kNoKey)
-          mac_key<LOGN, true>(sacc, nullptr, const_cast<const uint4*>(P4),
-                              reinterpret_cast<const uint4*>(key_ntt + ((size_t)i0.keyA * kKeyImages + img) * N), i0.signA < 0, li, pc);
-        const uint16_t kent = r ? i1.keyB : i1.keyA;
-        if (kent != kNoKey)
-          mac_key<LOGN, true>(sacc, nullptr, const_cast<const uint4*>(XL),
-                              reinterpret_cast<const uint4*>(key_ntt + ((size_t)kent * kKeyImages + img) * N),
-                              (r ? i1.signB : i1.signA) < 0, li, pc);
-        if (j == 1) {   // P is free now (row A's parked transform has just been used): the low half waits there
-#pragma unroll
-          for (int g = 0; g < E / 4; ++g) P4[g * 64 + li] = make_uint4(keep[4 * g], keep[4 * g + 1], keep[4 * g + 2], keep[4 * g + 3]);
-        }
-        wave_inv<LOGN>(sacc, li, lds, twf + kTableLen, pc);
-        if (j + 1 < njobs) {   // low half: residue mod p0 (lazy) -> the exact integer, |.| < 2^29
-#pragma unroll
-          for (int e = 0; e < E; ++e) {
-            const uint32_t dd = csub(sacc[e], pc.p);
-            keep[e] = dd >= T.crt.half1 ? dd - pc.p : dd;
-          }
-          continue;
-        }
-        if (one) {
-#pragma unroll
-          for (int e = 0; e < E; ++e) sacc[e] = crt_finish_zq(crt_fold0(sacc[e], 1, T.pc, T.crt), 1, T.crt);
-        } else {   // value = lo + 2^16 hi (mod q) in 32-bit arithmetic: hi * 2^16 by one Montgomery step with 2^48 mod q
-#pragma unroll
-          for (int g = 0; g < E / 4; ++g) {
-            const uint4 lv = P4[g * 64 + li];
-            const uint32_t ls[4] = {lv.x, lv.y, lv.z, lv.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const uint32_t dd = csub(sacc[4 * g + i], pc.p);
-              const int32_t rr = (int32_t)(dd >= T.crt.half1 ? dd - pc.p : dd);
-              const uint32_t hi_q = montq_u(zq_from_centered(rr, T.crt.q), T.crt.r48q, T.crt);
-              sacc[4 * g + i] = addq(hi_q, zq_from_centered((int32_t)ls[i], T.crt.q), T.crt.q);
-            }
-          }
-        }
-        finish_row<LOGN, 8>(sacc, prog, table_load(&prog->rows[r ? un.rowB : un.rowA]), ops, b, bo, lane, T, flags, nullptr);
-      }
-    }
   }
 }
 
@@ -1462,6 +1312,7 @@ shift_row_kernel(const Program* __restrict__ prog, const Operands ops, const Dev
     const uint32_t bo = ops.group > 1 ? b / ops.group : b;
     const Row row = prog->rows[rowi];
     const uint32_t qhalf = T.crt.qhalf;
+    const bool trusted = ops.trusted != 0;
     bool fault = false;
     {
       uint32_t res[E];
@@ -1472,10 +1323,10 @@ shift_row_kernel(const Program* __restrict__ prog, const Operands ops, const Dev
         const Term tm = prog->terms[row.term0 + t];
         int32_t a[E];
         uint32_t abad = 0, amx = 0;
-        load_pairs<LOGN>(a, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), lane, qhalf, abad, amx);
-        fault = fault || canon_fail(abad, amx, qhalf);
+        load_pairs<LOGN>(a, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), lane, qhalf, abad, amx, trusted);
+        if (!trusted) fault = fault || canon_fail(abad, amx, qhalf);
         shift_product<LOGN, true, false>(res, false, tm.sign < 0, a, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane,
-                                         slab, T, fault);
+                                         slab, T, fault, trusted);
       }
       // The sums move to the (now idle) image, each lane's pairs in its own 8-byte slots, so that the additions and
       // the store can run as a rolled loop with few registers and four 16-byte loads in flight per addition.
@@ -1502,8 +1353,16 @@ shift_row_kernel(const Program* __restrict__ prog, const Operands ops, const Dev
         const longlong2* __restrict__ p =
             reinterpret_cast<const longlong2*>(operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, N)) + g0 * 64 + lane;
         int32_t av[2 * GC];
+        if (trusted) {
 #pragma unroll
-        for (int g = 0; g < GC; ++g) canon_pair(p[g * 64], qhalf, in_bad, in_mx, av[2 * g], av[2 * g + 1]);
+          for (int g = 0; g < GC; ++g) {
+            const longlong2 t = p[g * 64];
+            av[2 * g] = (int32_t)t.x, av[2 * g + 1] = (int32_t)t.y;
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < GC; ++g) canon_pair(p[g * 64], qhalf, in_bad, in_mx, av[2 * g], av[2 * g + 1]);
+        }
         if (ad.sign >= 0) {
 #pragma unroll
           for (int i = 0; i < 2 * GC; ++i) r[i] = addq(r[i], zq_from_centered(av[i], q), q);
@@ -1548,7 +1407,7 @@ shift_row_kernel(const Program* __restrict__ prog, const Operands ops, const Dev
 template <int LOGN, int GM>
 __global__ void __launch_bounds__(256, RZK_GROUP_MIN_WAVES)
 row_group_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t* __restrict__ key_ntt,
-                 const double* __restrict__ key_inf, const DevTables* __restrict__ Tp,
+                 const double* __restrict__ key_l2, const DevTables* __restrict__ Tp,
                  const uint32_t* __restrict__ tw_all, uint32_t* __restrict__ scratch, uint8_t* __restrict__ flags,
                  const uint32_t ntasks) {
   using G = Geo<LOGN>;
@@ -1573,9 +1432,9 @@ row_group_kernel(const Program* __restrict__ prog, const Operands ops, const uin
     const uint32_t nt = row0.nterms;
     int np = kMaxPrimes;
     if (nt > 0) {
-      double bound[GM];
+      float bound[GM];
 #pragma unroll
-      for (int g = 0; g < GM; ++g) bound[g] = 0.0;
+      for (int g = 0; g < GM; ++g) bound[g] = 0.f;
 #pragma unroll 1
       for (int pi = 0; pi < np; ++pi) {
         const PrimeConsts pc = T.pc[pi];
@@ -1590,22 +1449,22 @@ row_group_kernel(const Program* __restrict__ prog, const Operands ops, const uin
         for (uint32_t t = 0; t < nt; ++t) {
           const Term tm0 = prog->terms[row0.term0 + t];
           uint32_t x[E];
-          double l1 = 0, linf = 0;
-          uint64_t sumsq = 0;
+          float nb = 0.f;
+          bool below = true;
           const bool chk = first && (tm0.kind & TERM_CHECK);
           int ln = lane;
           if (RZK_GROUP_OPAQUE) asm volatile("" : "+v"(ln));   // no hoisting of lane-dependent addresses (register budget)
           bool fault = false;
-          load_lift<LOGN>(x, operand_ptr(ops, tm0.b_op, tm0.b_off, b, bo, N), ln, pc, first, l1, linf, chk, sumsq,
-                          T.crt.qhalf, fault);
-          if (chk && sumsq >= ops.norm_limit && lane == 0) flags[bo] = 0;
+          load_lift<LOGN>(x, operand_ptr(ops, tm0.b_op, tm0.b_off, b, bo, N), ln, pc, first, nb, chk, ops.norm_limit, below,
+                          T.crt.qhalf, ops.trusted != 0, fault);
+          if (chk && !below && lane == 0) flags[bo] = 0;
           if (fault) input_fault(ops, flags, bo, lane);
           wave_fwd<LOGN>(x, ln, lds, twf, pc);
 #pragma unroll
           for (int g = 0; g < GM; ++g) {
             if ((uint32_t)g < cnt) {
               const Term tg = prog->terms[prog->rows[gd.row0 + g].term0 + t];
-              if (first) bound[g] += key_inf[tg.a_off] * l1;
+              if (first) bound[g] = bound_fma((float)key_l2[tg.a_off], nb, bound[g]);
               const uint4* __restrict__ kp =
                   reinterpret_cast<const uint4*>(key_ntt + ((size_t)tg.a_off * kKeyImages + pi) * N);
               if (tg.sign >= 0) {   // (one wave-uniform branch per term, not a select per coefficient)
@@ -1629,7 +1488,7 @@ row_group_kernel(const Program* __restrict__ prog, const Operands ops, const uin
           }
         }
         if (first) {
-          double mxb = bound[0];
+          float mxb = bound[0];
 #pragma unroll
           for (int g = 1; g < GM; ++g) mxb = bound[g] > mxb ? bound[g] : mxb;
           np = primes_for(mxb, T);
@@ -1669,7 +1528,7 @@ row_group_kernel(const Program* __restrict__ prog, const Operands ops, const uin
 template <int LOGN>
 __global__ void __launch_bounds__(64 * kBlockWaves)
 row_block_kernel(const Program* __restrict__ prog, const BlockPlan* __restrict__ plan, const Operands ops,
-                 const uint32_t* __restrict__ key_ntt, const double* __restrict__ key_inf,
+                 const uint32_t* __restrict__ key_ntt, const double* __restrict__ key_l2,
                  const DevTables* __restrict__ Tp, const uint32_t* __restrict__ tw_all, uint32_t* __restrict__ scratch,
                  uint8_t* __restrict__ flags, const uint32_t ntasks) {
   using G = Geo<LOGN>;
@@ -1680,7 +1539,7 @@ row_block_kernel(const Program* __restrict__ prog, const BlockPlan* __restrict__
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   uint32_t* staged = smem;                                                     // [kBlockMaxSlots][N]
   uint32_t* lds = smem + kBlockMaxSlots * N + wave * G::LDS_WORDS;             // this wave's transposition slab
-  double* norm1 = reinterpret_cast<double*>(smem + kBlockMaxSlots * N + kBlockWaves * G::LDS_WORDS);   // [slots]
+  float* norm1 = reinterpret_cast<float*>(smem + kBlockMaxSlots * N + kBlockWaves * G::LDS_WORDS);   // [slots]
   uint32_t* st = scratch + (size_t)blockIdx.x * (size_t)(2 * kBlockMaxRows) * N;   // [row][A|B][N]
   const DevTables& T = *Tp;
   const uint32_t nblocks = plan->nblocks;
@@ -1700,17 +1559,17 @@ row_block_kernel(const Program* __restrict__ prog, const BlockPlan* __restrict__
       for (uint32_t s = wave; s < bd.nslots; s += kBlockWaves) {
         const uint32_t gs = bd.slot0 + s;
         uint32_t x[E];
-        double l1 = 0, linf = 0;
-        uint64_t sumsq = 0;
+        float nb = 0.f;
+        bool below = true;
         const bool chk = first && plan->slot_check[gs] && ops.norm_limit;
         bool fault = false;
         int ln = lane;
         asm volatile("" : "+v"(ln));   // opaque lane ids: no lane-dependent addresses kept in registers across the steps
-        load_lift<LOGN>(x, operand_ptr(ops, plan->slot_op[gs], plan->slot_off[gs], b, bo, N), ln, pc, first, l1, linf,
-                        chk, sumsq, T.crt.qhalf, fault);
-        if (chk && sumsq >= ops.norm_limit && lane == 0) flags[bo] = 0;
+        load_lift<LOGN>(x, operand_ptr(ops, plan->slot_op[gs], plan->slot_off[gs], b, bo, N), ln, pc, first, nb, chk,
+                        ops.norm_limit, below, T.crt.qhalf, ops.trusted != 0, fault);
+        if (chk && !below && lane == 0) flags[bo] = 0;
         if (fault) input_fault(ops, flags, bo, lane);
-        if (first && lane == 0) norm1[s] = l1;
+        if (first && lane == 0) norm1[s] = nb;
         wave_fwd<LOGN>(x, ln, lds, twf, pc);
         uint32_t* dst = staged + s * N + ln;
 #pragma unroll
@@ -1718,14 +1577,14 @@ row_block_kernel(const Program* __restrict__ prog, const BlockPlan* __restrict__
       }
       __syncthreads();
       if (first) {
-        double mx = 0.0;
+        float mx = 0.f;
 #pragma unroll 1
         for (uint32_t r = 0; r < bd.nrows; ++r) {
           const Row row = prog->rows[bd.row0 + r];
-          double bound = 0.0;
+          float bound = 0.f;
 #pragma unroll 1
           for (uint32_t t = 0; t < row.nterms; ++t)
-            bound += key_inf[prog->terms[row.term0 + t].a_off] * norm1[plan->term_slot[row.term0 + t]];
+            bound = bound_fma((float)key_l2[prog->terms[row.term0 + t].a_off], norm1[plan->term_slot[row.term0 + t]], bound);
           mx = bound > mx ? bound : mx;
         }
         np = primes_for(mx, T);
@@ -1824,28 +1683,22 @@ fwd_slots_kernel(const SlotTable* __restrict__ slots, const Operands ops, const 
     const uint32_t bo = ops.group > 1 ? b / ops.group : b;
     const int64_t* __restrict__ src = operand_ptr(ops, slots->op[s], slots->off[s], b, bo, N);
     int32_t v[E];
-    uint32_t in_bad = 0, in_mx = 0;
+    if (ops.trusted) {
 #pragma unroll
-    for (int e = 0; e < E; ++e) v[e] = canon_lo_mx(src[G::j_p1(lane, e)], T.crt.qhalf, in_bad, in_mx);
-    if (canon_fail(in_bad, in_mx, T.crt.qhalf)) input_fault(ops, flags, bo, lane);
-    uint64_t sum = 0, sq = 0;
-    uint32_t mx = 0;
+      for (int e = 0; e < E; ++e) v[e] = (int32_t)src[G::j_p1(lane, e)];
+    } else {
+      uint32_t in_bad = 0, in_mx = 0;
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const uint32_t a = (uint32_t)(v[e] < 0 ? -v[e] : v[e]);
-      sum += a;
-      mx = a > mx ? a : mx;
-      const uint32_t ac = a < (1u << 24) ? a : (1u << 24);
-      sq += (uint64_t)ac * ac;
+      for (int e = 0; e < E; ++e) v[e] = canon_lo_mx(src[G::j_p1(lane, e)], T.crt.qhalf, in_bad, in_mx);
+      if (canon_fail(in_bad, in_mx, T.crt.qhalf)) input_fault(ops, flags, bo, lane);
     }
-    const double l1 = (double)wave_sum_u64(sum);
-    const double linf = (double)wave_max_u32(mx);
+    const float ss = sum_sq_f32<E>(v);
     if (lane == 0) {
-      norms[((size_t)b * nslots + s) * 2 + 0] = l1;
-      norms[((size_t)b * nslots + s) * 2 + 1] = linf;
+      norms[((size_t)b * nslots + s) * 2 + 0] = (double)norm2_upper(ss) * (1.0 + 1e-6);   // upper bound of the 2-norm (read back as float)
+      norms[((size_t)b * nslots + s) * 2 + 1] = 0.0;
     }
     if (slots->check[s] && ops.norm_limit) {
-      if (wave_sum_u64(sq) >= ops.norm_limit && lane == 0) flags[bo] = 0;
+      if (!norm_below<E>(v, ss, ops.norm_limit) && lane == 0) flags[bo] = 0;
     }
 #pragma unroll 1
     for (uint32_t pi = 0; pi < np_store; ++pi) {
@@ -1874,7 +1727,7 @@ fwd_slots_kernel(const SlotTable* __restrict__ slots, const Operands ops, const 
 template <int LOGN>
 __global__ void __launch_bounds__(256, RZK_ROW_MIN_WAVES)
 row_slots_kernel(const Program* __restrict__ prog, const SlotTable* __restrict__ slots, const Operands ops,
-                 const uint32_t* __restrict__ key_ntt, const double* __restrict__ key_inf,
+                 const uint32_t* __restrict__ key_ntt, const double* __restrict__ key_l2,
                  const DevTables* __restrict__ Tp, const uint32_t* __restrict__ tw_all,
                  const uint32_t* __restrict__ ws, const double* __restrict__ norms, uint32_t* __restrict__ scratch,
                  uint8_t* __restrict__ flags, const uint32_t batch, const uint32_t np_store) {
@@ -1905,17 +1758,16 @@ row_slots_kernel(const Program* __restrict__ prog, const SlotTable* __restrict__
     int np = 1;
     if (has_terms) {
       const double* __restrict__ nb = norms + (size_t)b * nslots * 2;
-      double bound = 0.0;
+      float bound = 0.f;
 #pragma unroll 1
       for (uint32_t t = 0; t < row.nterms; ++t) {
         const Term tm = prog->terms[row.term0 + t];
         const uint32_t sb = slots->term_b[row.term0 + t];
         if ((tm.kind & TERM_KIND_MASK) == TERM_VEC) {
           const uint32_t sa = slots->term_a[row.term0 + t];
-          const double u = nb[2 * sa] * nb[2 * sb + 1], v = nb[2 * sa + 1] * nb[2 * sb];
-          bound += u < v ? u : v;
+          bound = bound_fma((float)nb[2 * sa], (float)nb[2 * sb], bound);   // |a (*) b|_inf <= |a|_2 |b|_2
         } else {
-          bound += key_inf[tm.a_off] * nb[2 * sb];
+          bound = bound_fma((float)key_l2[tm.a_off], (float)nb[2 * sb], bound);
         }
       }
       np = primes_for(bound, T);
@@ -1950,12 +1802,12 @@ row_slots_kernel(const Program* __restrict__ prog, const SlotTable* __restrict__
           }
         } else {
           // more primes needed than were stored: transform in the wave for the missing ones
-          double unused = 0.0;
+          float unused = 0.f;
 #pragma unroll 1
           for (uint32_t t = 0; t < row.nterms; ++t) {
             Term tm = prog->terms[row.term0 + t];
             tm.kind &= TERM_KIND_MASK;   // norm predicate already evaluated by the forward pass
-            term_direct<LOGN, true>(acc, tm, ops, b, bo, lane, lds, twf, pc, pi, key_ntt, key_inf, false, unused, flags,
+            term_direct<LOGN, true>(acc, tm, ops, b, bo, lane, lds, twf, pc, pi, key_ntt, key_l2, false, unused, flags,
                                     T.crt.qhalf);
           }
         }
@@ -1967,8 +1819,7 @@ row_slots_kernel(const Program* __restrict__ prog, const SlotTable* __restrict__
 }
 
 // =============================================================================================
-// Key transform: centred key entries -> NTT domain (x N^-1, Montgomery form) for all three primes, plus the two
-// half images under prime 0 (rzk_core.h, kKeyImages)
+// Key transform: centred key entries -> NTT domain (x N^-1, Montgomery form) for all three primes
 // =============================================================================================
 template <int LOGN>
 __global__ void __launch_bounds__(256)
@@ -1985,21 +1836,14 @@ key_transform_kernel(const int64_t* __restrict__ key, uint32_t entries, uint32_t
   const uint32_t ntasks = entries * kKeyImages;
   for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
     const uint32_t entry = task / kKeyImages;
-    const int img = task % kKeyImages;
-    const int pi = img < kMaxPrimes ? img : 0;   // the two half images live under prime 0
+    const int pi = task % kKeyImages;
     const PrimeConsts pc = T.pc[pi];
     const int64_t* __restrict__ src = key + (uint64_t)entry * N;
     uint32_t x[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const int32_t kv = (int32_t)src[G::j_p1(lane, e)];
-      // K = Klo + 2^16 Khi with Klo in [-2^15, 2^15) (so |Khi| <= 2^15 for every centred K)
-      const int32_t klo = (int32_t)(((uint32_t)kv + 0x8000u) & 0xffffu) - 0x8000;
-      const int32_t v = img == kImgLo ? klo : (img == kImgHi ? (kv - klo) >> kSplitShift : kv);
-      x[e] = lift(v, pc);
-    }
+    for (int e = 0; e < E; ++e) x[e] = lift((int32_t)src[G::j_p1(lane, e)], pc);
     wave_fwd<LOGN>(x, lane, lds, tw_all + (size_t)(2 * pi) * kTableLen, pc);
-    uint4* __restrict__ dst = reinterpret_cast<uint4*>(key_ntt + ((uint64_t)entry * kKeyImages + img) * N);
+    uint4* __restrict__ dst = reinterpret_cast<uint4*>(key_ntt + ((uint64_t)entry * kKeyImages + pi) * N);
 #pragma unroll
     for (int g = 0; g < E / 4; ++g) {
       uint4 v;
@@ -2458,62 +2302,28 @@ size_t row_scratch_words(int logn, int num_cus) { return (size_t)num_cus * 8 * 4
 
 template <int LOGN, bool HAS_VEC, bool HAS_SHIFT>
 static int launch_units_t(const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, const Operands& ops,
-                          const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T, const uint32_t* d_tw,
-                          uint32_t* d_scratch, uint8_t* d_flags, uint32_t ntasks, uint32_t upt, uint32_t tpe, uint32_t wpt,
-                          const uint8_t* d_done) {
+                          const uint32_t* d_key_ntt, const double* d_key_l2, const DevTables* T, const uint32_t* d_tw,
+                          uint32_t* d_scratch, uint8_t* d_flags, uint32_t ntasks, uint32_t upt, uint32_t tpe, uint32_t wpt) {
   using G = Geo<LOGN>;
   constexpr int WPB = UnitCfg<LOGN>::WPB;
-  // per wave: transposition slab + P; then the workgroup's fairness table
-  const size_t lds = WPB * (size_t)(G::LDS_WORDS + G::N) * sizeof(uint32_t) + sizeof(FairTable);
+  // per wave: transposition slab + P
+  const size_t lds = WPB * (size_t)(G::LDS_WORDS + G::N) * sizeof(uint32_t);
   if (lds > 48 * 1024) {   // large dynamic LDS needs an opt-in; per device, so set before every launch (cheap, idempotent)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&unit_kernel<LOGN, HAS_VEC, HAS_SHIFT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  // scratch sizing: at most num_cus * 32 wave lines.  16-wave workgroups: one per CU at N = 1024 (133 KB of LDS), two
-  // at N = 512 — all resident, every wave walks its tasks with a grid stride.
-  const unsigned grid = WPB == 16 ? grid_for(ntasks, cfg.num_cus, 16, LOGN <= 9 ? 2 : 1) : grid_for(ntasks, cfg.num_cus, 4, 8);
+  // scratch sizing: at most num_cus * 32 wave lines; every wave walks its tasks with a grid stride
+  const unsigned grid = grid_for(ntasks, cfg.num_cus, 4, 8);
   hipLaunchKernelGGL((unit_kernel<LOGN, HAS_VEC, HAS_SHIFT>), dim3(grid), dim3(64 * WPB), lds, (hipStream_t)cfg.stream, d_prog,
-                     d_wp, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks, upt, tpe, wpt, d_done);
+                     d_wp, ops, d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks, upt, tpe, wpt);
   RZK_LAUNCH_CHECK();
   return 0;
-}
-
-template <int LOGN>
-static int launch_split_t(const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, const Operands& ops,
-                          const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T, const uint32_t* d_tw,
-                          uint32_t* d_scratch, uint8_t* d_flags, uint8_t* d_done, uint32_t ntasks) {
-  using G = Geo<LOGN>;
-  const size_t lds = 4 * (size_t)(G::LDS_WORDS + G::N) * sizeof(uint32_t);   // per wave: transposition slab + P
-  if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&split_kernel<LOGN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-  }
-  const unsigned grid = grid_for(ntasks, cfg.num_cus, 4, 8);   // <= num_cus * 8 blocks (scratch sizing)
-  hipLaunchKernelGGL((split_kernel<LOGN>), dim3(grid), dim3(256), lds, (hipStream_t)cfg.stream, d_prog, d_wp, ops, d_key_ntt,
-                     d_key_inf, T, d_tw, d_scratch, d_flags, d_done, ntasks);
-  RZK_LAUNCH_CHECK();
-  return 0;
-}
-
-int launch_split(int logn, const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, uint32_t nsplit,
-                 const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T,
-                 const uint32_t* d_tw, uint32_t* d_scratch, uint8_t* d_flags, uint8_t* d_done, uint64_t batch) {
-  if (batch == 0 || nsplit == 0) return 0;
-  if (batch * nsplit >= (1ull << 32)) return -2;
-  const uint32_t ntasks = (uint32_t)(batch * nsplit);
-  switch (logn) {
-    case 9: return launch_split_t<9>(cfg, d_prog, d_wp, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, d_done, ntasks);
-    case 10: return launch_split_t<10>(cfg, d_prog, d_wp, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, d_done, ntasks);
-    case 11: return launch_split_t<11>(cfg, d_prog, d_wp, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, d_done, ntasks);
-  }
-  return -1;
 }
 
 template <int LOGN, bool HAS_SHIFT>
 static int launch_rows_t(const LaunchCfg& cfg, const Program* d_prog, const Operands& ops, const uint32_t* d_key_ntt,
-                         const double* d_key_inf, const DevTables* T, const uint32_t* d_tw, uint32_t* d_scratch,
+                         const double* d_key_l2, const DevTables* T, const uint32_t* d_tw, uint32_t* d_scratch,
                          uint8_t* d_flags, uint32_t ntasks) {
   using G = Geo<LOGN>;
   const size_t lds = 4 * (size_t)(G::LDS_WORDS + G::N) * sizeof(uint32_t);   // per wave: transposition slab + state word A
@@ -2524,18 +2334,18 @@ static int launch_rows_t(const LaunchCfg& cfg, const Program* d_prog, const Oper
   }
   const unsigned grid = grid_for(ntasks, cfg.num_cus, 4, 8);   // <= num_cus * 8 blocks (scratch sizing)
   hipLaunchKernelGGL((row_kernel<LOGN, HAS_SHIFT>), dim3(grid), dim3(256), lds, (hipStream_t)cfg.stream, d_prog, ops,
-                     d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
+                     d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks);
   RZK_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_rows(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows, bool has_shift, const Operands& ops,
-                const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T, const uint32_t* d_tw,
+                const uint32_t* d_key_ntt, const double* d_key_l2, const DevTables* T, const uint32_t* d_tw,
                 uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch) {
   if (batch == 0 || nrows == 0) return 0;
   if (batch * nrows >= (1ull << 32)) return -2;
   const uint32_t ntasks = (uint32_t)(batch * nrows);
-#define RZK_ROWS_ARGS cfg, d_prog, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks
+#define RZK_ROWS_ARGS cfg, d_prog, ops, d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks
   switch (logn) {
     case 9: return has_shift ? launch_rows_t<9, true>(RZK_ROWS_ARGS) : launch_rows_t<9, false>(RZK_ROWS_ARGS);
     case 10: return has_shift ? launch_rows_t<10, true>(RZK_ROWS_ARGS) : launch_rows_t<10, false>(RZK_ROWS_ARGS);
@@ -2547,15 +2357,15 @@ int launch_rows(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t 
 
 int launch_units(int logn, const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, uint32_t nunits,
                  uint32_t units_per_task, uint32_t work_per_entry, bool has_vec, bool has_shift, const Operands& ops,
-                 const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T, const uint32_t* d_tw,
-                 uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch, const uint8_t* d_done) {
+                 const uint32_t* d_key_ntt, const double* d_key_l2, const DevTables* T, const uint32_t* d_tw,
+                 uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch) {
   if (batch == 0 || nunits == 0) return 0;
   if (units_per_task == 0) units_per_task = 1;
   const uint32_t tpe = (nunits + units_per_task - 1) / units_per_task;   // tasks per batch entry
   if (batch * tpe >= (1ull << 32)) return -2;   // task index is 32-bit
   const uint32_t ntasks = (uint32_t)(batch * tpe);
   const uint32_t wpt = (work_per_entry + tpe - 1) / tpe;   // transforms per task (estimate, for the progress priorities)
-#define RZK_UNIT_ARGS cfg, d_prog, d_wp, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks, units_per_task, tpe, wpt, d_done
+#define RZK_UNIT_ARGS cfg, d_prog, d_wp, ops, d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks, units_per_task, tpe, wpt
 #define RZK_UNIT_CASE(L)                                                                                            \
   case L:                                                                                                           \
     if (has_shift)                                                                                                  \
@@ -2604,27 +2414,27 @@ size_t group_scratch_words(int logn, int num_cus) {
 
 template <int LOGN>
 static int launch_groups_t(const LaunchCfg& cfg, const Program* d_prog, const Operands& ops, const uint32_t* d_key_ntt,
-                           const double* d_key_inf, const DevTables* T, const uint32_t* d_tw, uint32_t* d_scratch,
+                           const double* d_key_l2, const DevTables* T, const uint32_t* d_tw, uint32_t* d_scratch,
                            uint8_t* d_flags, uint32_t ntasks) {
   using G = Geo<LOGN>;
   constexpr int GM = LOGN >= 11 ? 2 : RZK_GROUP_GM;   // accumulators per wave (N = 2048 is never grouped by the host)
   hipLaunchKernelGGL((row_group_kernel<LOGN, GM>), dim3(grid_for(ntasks, cfg.num_cus)), dim3(256),
-                     4 * G::LDS_WORDS * sizeof(uint32_t), (hipStream_t)cfg.stream, d_prog, ops, d_key_ntt, d_key_inf, T,
+                     4 * G::LDS_WORDS * sizeof(uint32_t), (hipStream_t)cfg.stream, d_prog, ops, d_key_ntt, d_key_l2, T,
                      d_tw, d_scratch, d_flags, ntasks);
   RZK_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_row_groups(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t ngroups, const Operands& ops,
-                      const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T, const uint32_t* d_tw,
+                      const uint32_t* d_key_ntt, const double* d_key_l2, const DevTables* T, const uint32_t* d_tw,
                       uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch) {
   if (batch == 0 || ngroups == 0) return 0;
   if (batch * ngroups >= (1ull << 32)) return -2;
   const uint32_t ntasks = (uint32_t)(batch * ngroups);
   switch (logn) {
-    case 9: return launch_groups_t<9>(cfg, d_prog, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
-    case 10: return launch_groups_t<10>(cfg, d_prog, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
-    case 11: return launch_groups_t<11>(cfg, d_prog, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
+    case 9: return launch_groups_t<9>(cfg, d_prog, ops, d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks);
+    case 10: return launch_groups_t<10>(cfg, d_prog, ops, d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks);
+    case 11: return launch_groups_t<11>(cfg, d_prog, ops, d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks);
   }
   return -1;
 }
@@ -2635,7 +2445,7 @@ size_t block_scratch_words(int logn, int num_cus) {
 
 template <int LOGN>
 static int launch_blocks_t(const LaunchCfg& cfg, const Program* d_prog, const BlockPlan* d_plan, const Operands& ops,
-                           const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T, const uint32_t* d_tw,
+                           const uint32_t* d_key_ntt, const double* d_key_l2, const DevTables* T, const uint32_t* d_tw,
                            uint32_t* d_scratch, uint8_t* d_flags, uint32_t ntasks) {
   using G = Geo<LOGN>;
   const size_t lds = ((size_t)kBlockMaxSlots * G::N + (size_t)kBlockWaves * G::LDS_WORDS) * sizeof(uint32_t) +
@@ -2650,27 +2460,27 @@ static int launch_blocks_t(const LaunchCfg& cfg, const Program* d_prog, const Bl
   }
   uint32_t grid = ntasks < (uint32_t)cfg.num_cus * 2 ? ntasks : (uint32_t)cfg.num_cus * 2;   // scratch: num_cus * 2 lines
   hipLaunchKernelGGL((row_block_kernel<LOGN>), dim3(grid), dim3(64 * kBlockWaves), lds, (hipStream_t)cfg.stream, d_prog,
-                     d_plan, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
+                     d_plan, ops, d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks);
   RZK_LAUNCH_CHECK();
   return 0;
 }
 
 int launch_row_blocks(int logn, const LaunchCfg& cfg, const Program* d_prog, const BlockPlan* d_plan, uint32_t nblocks,
-                      const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T,
+                      const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_l2, const DevTables* T,
                       const uint32_t* d_tw, uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch) {
   if (batch == 0 || nblocks == 0) return 0;
   if (batch * nblocks >= (1ull << 32)) return -2;
   const uint32_t ntasks = (uint32_t)(batch * nblocks);
   switch (logn) {
-    case 10: return launch_blocks_t<10>(cfg, d_prog, d_plan, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
-    case 11: return launch_blocks_t<11>(cfg, d_prog, d_plan, ops, d_key_ntt, d_key_inf, T, d_tw, d_scratch, d_flags, ntasks);
+    case 10: return launch_blocks_t<10>(cfg, d_prog, d_plan, ops, d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks);
+    case 11: return launch_blocks_t<11>(cfg, d_prog, d_plan, ops, d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks);
   }
   return -1;
 }
 
 template <int LOGN>
 static int launch_slots_t(const LaunchCfg& cfg, const Program* d_prog, const SlotTable* d_slots, uint32_t nslots,
-                          const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_inf, const DevTables* T,
+                          const Operands& ops, const uint32_t* d_key_ntt, const double* d_key_l2, const DevTables* T,
                           const uint32_t* d_tw, uint32_t* d_ws, double* d_norms, uint32_t* d_scratch, uint8_t* d_flags,
                           uint32_t batch, uint32_t np_store) {
   using G = Geo<LOGN>;
@@ -2682,7 +2492,7 @@ static int launch_slots_t(const LaunchCfg& cfg, const Program* d_prog, const Slo
   unsigned grid = (unsigned)cfg.num_cus * 8;   // multiple of 8: the XCD-class dealing needs whole classes
   grid -= grid % 8;
   hipLaunchKernelGGL(row_slots_kernel<LOGN>, dim3(grid), dim3(256), 4 * (G::LDS_WORDS + G::N) * sizeof(uint32_t),
-                     (hipStream_t)cfg.stream, d_prog, d_slots, ops, d_key_ntt, d_key_inf, T, d_tw, d_ws, d_norms,
+                     (hipStream_t)cfg.stream, d_prog, d_slots, ops, d_key_ntt, d_key_l2, T, d_tw, d_ws, d_norms,
                      d_scratch, d_flags, batch, np_store);
   RZK_LAUNCH_CHECK();
   return 0;
@@ -2690,15 +2500,15 @@ static int launch_slots_t(const LaunchCfg& cfg, const Program* d_prog, const Slo
 
 int launch_row_program_slots(int logn, const LaunchCfg& cfg, const Program* d_prog, const SlotTable* d_slots,
                              uint32_t nslots, const Operands& ops, const uint32_t* d_key_ntt,
-                             const double* d_key_inf, const DevTables* T, const uint32_t* d_tw, uint32_t* d_ws,
+                             const double* d_key_l2, const DevTables* T, const uint32_t* d_tw, uint32_t* d_ws,
                              double* d_norms, uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch,
                              uint32_t np_store) {
   if (batch == 0) return 0;
   if (batch * nslots >= (1ull << 32) || batch >= (1ull << 31)) return -2;
   switch (logn) {
-    case 9: return launch_slots_t<9>(cfg, d_prog, d_slots, nslots, ops, d_key_ntt, d_key_inf, T, d_tw, d_ws, d_norms, d_scratch, d_flags, (uint32_t)batch, np_store);
-    case 10: return launch_slots_t<10>(cfg, d_prog, d_slots, nslots, ops, d_key_ntt, d_key_inf, T, d_tw, d_ws, d_norms, d_scratch, d_flags, (uint32_t)batch, np_store);
-    case 11: return launch_slots_t<11>(cfg, d_prog, d_slots, nslots, ops, d_key_ntt, d_key_inf, T, d_tw, d_ws, d_norms, d_scratch, d_flags, (uint32_t)batch, np_store);
+    case 9: return launch_slots_t<9>(cfg, d_prog, d_slots, nslots, ops, d_key_ntt, d_key_l2, T, d_tw, d_ws, d_norms, d_scratch, d_flags, (uint32_t)batch, np_store);
+    case 10: return launch_slots_t<10>(cfg, d_prog, d_slots, nslots, ops, d_key_ntt, d_key_l2, T, d_tw, d_ws, d_norms, d_scratch, d_flags, (uint32_t)batch, np_store);
+    case 11: return launch_slots_t<11>(cfg, d_prog, d_slots, nslots, ops, d_key_ntt, d_key_l2, T, d_tw, d_ws, d_norms, d_scratch, d_flags, (uint32_t)batch, np_store);
   }
   return -1;
 }

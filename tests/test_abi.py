@@ -71,3 +71,15 @@ def test_product_package_does_not_import_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "rzk_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_abi_version_matches_header():
+    """A stale or variant .so must fail at load time: the binding checks rzk_abi_version()."""
+    import re
+
+    from ring_zk_amd import _lib
+
+    hdr = open(os.path.join(ROOT, "include", "rzk.h")).read()
+    m = re.search(r"#define RZK_ABI_VERSION (\d+)u", hdr)
+    assert m and int(m.group(1)) == _lib.ABI_VERSION
+    assert int(_lib.lib().rzk_abi_version()) == _lib.ABI_VERSION

@@ -228,14 +228,16 @@ def test_forced_kernel_paths_vs_oracle(torch_mod, cfg):
     check_sum_cycle(torch_mod, ctx, A, 2, V, 602 + n, device_too=False)
 
 
-# ---- split_kernel (RZK_SPLIT=1): one prime per 16-bit key half for operands of small 1-norm -----------------------
+# ---- operands of very different sizes in one batch: the per-proof prime count (1, 2 or 3) is decided from the norms
+@pytest.mark.parametrize("upt", [0, 64])
 @pytest.mark.parametrize("N", [512, 1024, 2048])
-def test_split_kernel_vs_oracle(torch_mod, N):
-    """The per-proof decision of split_kernel: taken when 2^15 * (|r_1|_1 + |r_2|_1) fits prime 0, refused (and the
-    unit left to unit_kernel) one step beyond; a sparse operand that one prime covers outright; ternary r as the
-    commitments use it.  commit.rs:109-125 (oracle: O.commit)."""
+def test_prime_count_per_proof_vs_oracle(torch_mod, N, upt):
+    """Randomness of six different magnitudes in one batch — ternary, two sparse spikes, constant 8, one large pair, a
+    single -1, full range — so that neighbouring proofs of one launch need 1, 2 and 3 auxiliary primes; upt = 64 walks
+    all units of a proof in ONE wavefront (the path the 4096-proof batches take) at this small batch.
+    commit.rs:109-125 (oracle: O.commit)."""
     n, k, l = 1, 3, 1
-    ctx = make_ctx(N, n, k, l, env={"RZK_SPLIT": 1})
+    ctx = make_ctx(N, n, k, l, env={"RZK_UPT": upt} if upt else {})
     P = P_of(ctx)
     rng = np.random.default_rng(700 + N)
     A = synth.key(rng, N, n, k, l)
@@ -243,14 +245,14 @@ def test_split_kernel_vs_oracle(torch_mod, N):
     B = 6
     x = synth.uniform(rng, (B, l, N))
     r = np.zeros((B, k, N), dtype=np.int64)
-    r[0] = synth.small(rng, (k, N))                       # ternary: split
-    r[1, 1, 0], r[1, 2, 3] = 16000, -383                  # 1-norm 16383 over the two product operands: split
+    r[0] = synth.small(rng, (k, N))                       # ternary
+    r[1, 1, 0], r[1, 2, 3] = 16000, -383                  # two spikes
     r[1, 0] = synth.small(rng, (N,))
     r[2, 1, :N] = 8
-    r[2, 2, :N] = 8                                       # 1-norm 16 N: 8192 / 16384 / 32768 -> split, split, refused
-    r[3, 1, 0], r[3, 1, 1] = 16383, 1                     # 1-norm 16384: refused at every N (general path)
-    r[4, 2, 5] = -1                                       # a single -1: tiny 1-norm
-    r[5] = synth.uniform(rng, (k, N))                     # full range: refused
+    r[2, 2, :N] = 8                                       # constant 8
+    r[3, 1, 0], r[3, 1, 1] = 16383, 1
+    r[4, 2, 5] = -1                                       # a single -1: one prime suffices
+    r[5] = synth.uniform(rng, (k, N))                     # full range: three primes
     y = synth.gauss(rng, (B, k, N), P.sigma)
     cm, okc = ctx.commit(x, r)
     c, t, ok = ctx.open_commit(x, r, y)

@@ -22,8 +22,7 @@ KNOBS = [
     {"RZK_SHIFT": 0},
     {"RZK_PAIRS": 0},
     {"RZK_VEC_ROWS": 0},
-    {"RZK_SPLIT": 1},
-    {"RZK_UPT": 1},
+    {"RZK_UPT": 64},   # all units of a proof in one wavefront (what batches >= 4096 take), here at batch <= 5
     {"RZK_SLOT_SHARE_MIN": 0, "RZK_ROW_GROUPS": 0},
     {"RZK_BLOCK_MIN_LOGN": 10},
 ]

@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--broadcast-key", type=int, default=1,
                     help="N > 1: rank 0 generates the key and broadcasts the [a1;a2] slab (RCCL) instead of every rank "
                          "regenerating it from the seed")
+    ap.add_argument("--extra-steps", type=int, default=-1,
+                    help="steps of each of the two secondary timed regions (randomness drawn inside the step; trusted-producer "
+                         "mode): -1 = min(steps, 100), 0 = skip them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="target length of the CPU baseline sample")
     return ap.parse_args()
@@ -342,13 +345,33 @@ def main():
     torch.cuda.synchronize()
     accepted = [0, 0]   # accept / commit-ok counts of the last step
 
-    def step(marks=None, count=False):
+    sid_fresh = [10_000]
+
+    def redraw_randomness(I):
+        """The draws the reference's benches time with the phases (benches/bench.rs:41-47: commit() with its r loop,
+        commit.rs:98-107; the prover's Gaussian y, open.rs:88-94; generate_challenge's d, open.rs:143-158): fresh
+        r, y (and r', y' ...) and d from the device samplers, the message x / g stays."""
+        J = dict(I)
+        sid = sid_fresh[0]
+        sid_fresh[0] += 16
+        for i, key in enumerate(sorted(I)):
+            if key in ("r", "rp", "rs"):
+                J[key] = ctx.sample_uniform(seed, sid + i, ctx.b, I[key].shape[:-1])
+            elif key in ("y", "yp", "ys"):
+                J[key] = ctx.sample_gauss(seed, sid + i, float(sig), I[key].shape[:-1])
+            elif key == "d":
+                J[key] = ctx.sample_challenge(seed, sid + i, I[key].shape[:-1])
+        return J
+
+    def step(marks=None, count=False, sample=False):
         """One pass over the batch.  marks: list collecting launch-count marks per phase (profiled steps);
         count: also add up the verdict flags of every chunk (done for the last timed step only: two small torch
-        reductions per chunk that are not part of the path)."""
+        reductions per chunk that are not part of the path); sample: draw the step's randomness inside the step."""
         tot_ok = tot_acc = None
         for ci in range(nchunks):
             I = resident if resident is not None else draw(ci)
+            if sample and resident is not None:
+                I = redraw_randomness(I)
             if marks is not None:
                 m = [ctx.prof_count()]
                 for _name in phases(I):
@@ -441,6 +464,43 @@ def main():
     proofs = B * world * args.steps
     value = proofs / elapsed
 
+    # ---- secondary timed regions (same bracket: barrier + synchronize on both sides, max over ranks) ----------------
+    # (a) the step's randomness drawn INSIDE the step, as the reference's criterion benches do; (b) trusted-producer
+    # mode (rzk_ctx_trust_device_outputs): the cycle's operands are the library's own device outputs, the per-
+    # coefficient range test is skipped.  `value` stays the checked, pre-sampled number.
+    extra = args.extra_steps if args.extra_steps >= 0 else min(args.steps, 100)
+    secondary = {}
+    if extra > 0:
+        def timed(nsteps, **kw):
+            for _ in range(max(2, nsteps // 10)):
+                step(**kw)
+            barrier()
+            t1 = time.perf_counter()
+            for i in range(nsteps):
+                res = step(count=(i + 1 == nsteps), **kw)
+            barrier()
+            el = time.perf_counter() - t1
+            ok2, acc2 = res
+            return el, int(acc2.item()), int(ok2.item())
+
+        if resident is not None:
+            el, acc2, ok2 = timed(extra, sample=True)
+            # fresh r can fail check_commit_constraint only with negligible probability at b = 1; every proof whose
+            # commit was ok must verify
+            assert acc2 == ok2, f"rank {rank}: sampled cycle: {acc2} accepted of {ok2} commit-ok"
+            el, acc_sum, _pr = shard.reduce_result(dist, el, acc2, red_dev, gather=True)
+            secondary["value_with_sampling"] = B * world * extra / el
+            secondary["with_sampling"] = {"steps": extra, "ms_per_step": el / extra * 1e3, "accepted_last_step": acc_sum,
+                                          "drawn_in_step": "r, y (prover randomness) and d (challenge) by rzk_sample_*_dev; x resident"}
+        ctx.trust_device_outputs(True)
+        el, acc2, ok2 = timed(extra)
+        ctx.trust_device_outputs(False)
+        assert acc2 == B and ok2 == B
+        el, _a, _pr = shard.reduce_result(dist, el, acc2, red_dev, gather=True)
+        secondary["value_trusted"] = B * world * extra / el
+        secondary["trusted"] = {"steps": extra, "ms_per_step": el / extra * 1e3,
+                                "mode": "rzk_ctx_trust_device_outputs(1): canonical test of loaded coefficients skipped"}
+
     roofline = None
     ntt = None
     units = None
@@ -451,8 +511,16 @@ def main():
             for _ in range(max(3, min(args.steps, 10))):
                 step(marks)
         durs = ctx.prof_read_all()
+        kinfo = ctx.prof_read_kernels()
         ctx.prof_enable(False)
         launches = len(durs)
+        # per kernel (template instance): launches, time and algorithmic bytes as the library reports them per launch
+        per_kernel = {}
+        for (kname, kbytes), dur in zip(kinfo, durs):
+            e = per_kernel.setdefault(kname, {"launches": 0, "us": 0.0, "bytes": 0})
+            e["launches"] += 1
+            e["us"] += dur
+            e["bytes"] += kbytes
         nprof = max(len(marks), 1)
         # per phase: the durations of its row-program launches, averaged over the profiled chunks
         names = ("commit", "response", "verify")
@@ -468,31 +536,35 @@ def main():
         phase_bytes = {name: polys[name] * 8 * N * Bc for name in names}
         cycle_bytes = sum(phase_bytes.values())
         cycle_us = sum(phase_us.values())
-        # the dominant kernel = the single launch with the largest duration; its own bytes and duration give `frac`.
-        # For the Open cycle every phase is one launch, so its bytes are the phase's; for Linear / Sum a phase is
-        # several launches and the phase's bytes / phase's time are reported for the phase that holds the launch.
-        dom_phase = max(names, key=lambda nm: max(phase_launch_us[nm]) if phase_launch_us.get(nm) else 0.0)
-        dom_us = max(phase_launch_us[dom_phase])
-        single = len(phase_launch_us[dom_phase]) == 1
-        dom_bytes = phase_bytes[dom_phase]
-        dom_time = dom_us if single else phase_us[dom_phase]
-        achieved = dom_bytes / (dom_time * 1e-6) / 1e9
-        kernel_names = {"open": {"commit": "unit_kernel<log2 N, false, false> (commit rows c, t: pair unit + single unit per proof)",
-                                 "response": "shift_row_kernel<log2 N> (z = y + r (.) d as rotations)",
-                                 "verify": "unit_kernel<log2 N, false, true> (a1.z - c1 (.) d - t == 0, rotation term)"}}
+        # the dominant kernel = the kernel (template instance) with the largest share of the profiled time; `frac` is
+        # ITS algorithmic bytes over ITS time (both summed over its launches: the library reports, per launch, which
+        # kernel ran and 8 N x (distinct polynomials read + rows stored) x batch entries)
+        dom_name = max(per_kernel, key=lambda nm: per_kernel[nm]["us"]) if per_kernel else None
+        dom = per_kernel.get(dom_name, {"launches": 1, "us": 1.0, "bytes": 0})
+        dom_phase = max(names, key=lambda nm: phase_us.get(nm, 0.0))
+        dom_time = dom["us"] / max(dom["launches"], 1)
+        dom_bytes = dom["bytes"] / max(dom["launches"], 1)
+        achieved = dom["bytes"] / (dom["us"] * 1e-6) / 1e9
+        total_prof_us = sum(e["us"] for e in per_kernel.values()) or 1.0
+        kernels_out = {nm: {"launches_per_step": e["launches"] / nprof, "avg_launch_us": e["us"] / e["launches"],
+                            "share_of_kernel_time": e["us"] / total_prof_us,
+                            "algorithmic_bytes_per_launch": e["bytes"] / e["launches"],
+                            "frac_of_hbm_peak": e["bytes"] / (e["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS}
+                       for nm, e in sorted(per_kernel.items(), key=lambda kv: -kv[1]["us"])}
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-        if args.workload == "open" and N == 1024 and os.path.exists(pmc_path):
+        pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+        if os.path.exists(pmc_path):
             try:
                 pj = json.load(open(pmc_path))
-                traffic = pj.get("hbm_bytes_per_launch", {}).get(dom_phase)
-                traffic_src = "imported from profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
-                              "this same command, corrected as the guide prescribes; not measured in this run)"
+                ent = pj.get("kernels", {}).get(dom_name) if pj.get("workload") == f"{args.workload}-{N}-{args.shape}" else None
+                if ent:
+                    traffic = ent.get("hbm_bytes_per_launch")
+                    traffic_src = "imported from profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
+                                  "this same command, corrected as the guide prescribes; not measured in this run)"
             except Exception:
                 traffic = None
         roofline = {
-            "kernel": kernel_names.get(args.workload, {}).get(dom_phase, f"{dom_phase} phase ({len(phase_launch_us[dom_phase])} row-program launches)")
-                      .replace("log2 N", str(N.bit_length() - 1)),
+            "kernel": dom_name,
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
@@ -502,7 +574,8 @@ def main():
             "traffic_source": traffic_src,
             "avg_launch_us": dom_time,
             "algorithmic_bytes_per_launch": dom_bytes,
-            "scope": "the dominant kernel's own launch" if single else f"all launches of the {dom_phase} phase",
+            "scope": "the dominant kernel's own launches (algorithmic bytes and HIP-event durations of exactly those)",
+            "kernels": kernels_out,
             "phase_us": phase_us,
             "phase_frac": {nm: (phase_bytes[nm] / (phase_us[nm] * 1e-6) / 1e9) / HBM_PEAK_GBS if phase_us.get(nm) else None
                            for nm in names},
@@ -548,6 +621,7 @@ def main():
         out = {
             "metric": "proofs/sec (commit+challenge+response+verify), N=1024, batch=4096; NTT GB/s vs HBM peak",
             "value": value,
+            **{k_: v_ for k_, v_ in secondary.items() if k_.startswith("value_")},
             "unit": "proofs/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -574,6 +648,10 @@ def main():
                                + ("broadcast from rank 0" if world > 1 and args.broadcast_key else "generated from the same seed on every rank"),
                 "accepted": tot_acc,
                 "accepted_per_rank": per_rank,
+                "secondary": {k_: v_ for k_, v_ in secondary.items() if not k_.startswith("value_")},
+                "values": "value = every coefficient range-checked, randomness pre-sampled (the headline); value_with_sampling = "
+                          "r, y and d drawn by the device samplers inside every timed step (what benches/bench.rs times); "
+                          "value_trusted = trusted-producer mode, randomness pre-sampled",
             },
             "roofline": roofline,
             "units": units,

@@ -101,6 +101,7 @@ struct rzk_ctx {
   bool use_groups = true;
   uint32_t units_per_task = 0;         // 0 = automatic (RZK_UPT overrides, tuning)
   bool vec_rows = true;                // programs with vector x vector products: row_kernel (RZK_VEC_ROWS=0: unit_kernel)
+  bool pair_poly = true;               // N = 2048: two wavefronts per polynomial (RZK_PAIR_POLY=0: one, the round-2 kernels)
   bool trusted = false;                // rzk_ctx_trust_device_outputs: skip the canonical test of loaded coefficients
   bool use_pairs = true;               // unit_kernel: pair rows that share their last operand (RZK_PAIRS=0 turns it off, tuning)
   int group_max = 1;                   // rows per group of row_group_kernel (group_max_for; RZK_GROUP_MAX overrides, tuning)
@@ -169,7 +170,7 @@ uint64_t isqrt_u64(uint64_t x) {
 
 LaunchCfg cfg_of(rzk_ctx* c) {
   (void)hipSetDevice(c->device);   // the calling thread may have another current device
-  return LaunchCfg{(void*)c->stream, c->num_cus};
+  return LaunchCfg{(void*)c->stream, c->num_cus, c->pair_poly ? 1 : 0};
 }
 
 int arena_reserve(rzk_ctx* c, Arena& a, size_t bytes) {
@@ -819,13 +820,18 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
     if (c->prof_info.size() <= c->prof_used) c->prof_info.resize(c->prof_used + 1);
     rzk_ctx::ProfInfo& pi = c->prof_info[c->prof_used];
     const std::string L = std::to_string(c->logn);
+    const bool pairs = c->logn == 11 && c->pair_poly;   // two wavefronts per polynomial
+    const std::string tf = c->trusted ? "true" : "false";
     if (c->small) pi.kernel = "row_kernel_small";
-    else if (dp.shift) pi.kernel = "shift_row_kernel<" + L + ">";
-    else if (dp.nblocks) pi.kernel = "row_block_kernel<" + L + ">";
+    else if (dp.shift) pi.kernel = "shift_row_kernel<" + L + ", " + tf + ">";
+    else if (dp.nblocks) pi.kernel = "row_block_kernel<" + L + (pairs ? ", BlockPairTeam>" : ">");
     else if (dp.ngroups) pi.kernel = "row_group_kernel<" + L + ", " + std::to_string(c->logn >= 11 ? 2 : RZK_GROUP_GM) + ">";
     else if (dp.d_slots) pi.kernel = "fwd_slots_kernel<" + L + "> + row_slots_kernel<" + L + ">";
-    else if (dp.has_vec && c->vec_rows) pi.kernel = "row_kernel<" + L + ", " + (dp.has_shift ? "true" : "false") + ">";
-    else pi.kernel = "unit_kernel<" + L + ", " + (dp.has_vec ? "true" : "false") + ", " + (dp.has_shift ? "true" : "false") + ">";
+    else if (dp.has_vec && c->vec_rows)
+      pi.kernel = "row_kernel<" + L + ", " + (dp.has_shift ? "true" : "false") + (pairs ? ", PairTeam>" : ">");
+    else
+      pi.kernel = "unit_kernel<" + L + ", " + (dp.has_vec ? "true" : "false") + ", " + (dp.has_shift ? "true" : "false") +
+                  (pairs ? ", PairTeam>" : ">");
     pi.bytes = 0;
     for (size_t i = 0; i < specs.size(); ++i)
       pi.bytes += (uint64_t)dp.polys_in[i] * (specs[i].outer ? batch / (group ? group : 1) : batch);
@@ -1059,6 +1065,7 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
   if (const char* e = std::getenv("RZK_PAIRS")) c->use_pairs = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_UPT")) c->units_per_task = (uint32_t)std::atoi(e);
   if (const char* e = std::getenv("RZK_VEC_ROWS")) c->vec_rows = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RZK_PAIR_POLY")) c->pair_poly = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_BLOCK_MIN_LOGN")) c->block_min_logn = (uint32_t)std::atoi(e);   // 12 = never
 
   // twiddle tables: 3 primes x {fwd, inv} x kTableLen

@@ -110,92 +110,119 @@ RZK_HD void bfly_inv(uint32_t& X, uint32_t& Y, uint32_t w, const PrimeConsts& pc
 }
 
 // ---- geometry ------------------------------------------------------------------------------------
-template <int LOGN>
+// A TEAM of 2^LL threads transforms one polynomial: LL = 6 is one wavefront (every size), LL = 7 two wavefronts that
+// share one LDS slab (N = 2048: 16 coefficients per thread instead of 32 — the register footprint, and with it the
+// occupancy, of the N = 1024 kernels).  `lane` below is the thread's index inside its team (0 .. 2^LL - 1).
+template <int LOGN, int LL = 6>
 struct Geo {
-  static_assert(LOGN >= 9 && LOGN <= 11, "one wavefront per polynomial supports N = 512, 1024, 2048");
+  static_assert(LL == 6 || LL == 7, "teams of one or two wavefronts");
+  static_assert(LOGN >= 9 && LOGN <= 11, "N = 512, 1024, 2048");
+  static constexpr int LOGLANES = LL;
+  static constexpr int LANES = 1 << LL;
   static constexpr int N = 1 << LOGN;
-  static constexpr int LE = LOGN - 6;      // local bits per phase
-  static constexpr int E = 1 << LE;        // coefficients per lane
-  static constexpr int R3 = LOGN - 2 * LE; // stages left for phase 3 (= 6 - LE)
-  static constexpr int LOSH = 6 - LE;      // low lane bits of phase 2
+  static constexpr int LE = LOGN - LL;     // local bits per phase
+  static constexpr int E = 1 << LE;        // coefficients per thread
+  static constexpr int R3 = LOGN - 2 * LE; // stages left for phase 3
+  static constexpr int LOSH = LL - LE;     // low thread bits of phase 2
+  static_assert(LE >= 3 && R3 >= 0 && R3 <= LE && LOSH >= 0, "three register phases must cover log2 N stages");
   // LDS word address of coefficient j: one pad word per 32 keeps all three access patterns
   // (phase-1 rows, phase-2 strided, phase-3 blocked) bank-conflict free for ds_*_b32
-  // (N = 1024, 2048) or 2-way (N = 512); see tools/lds_conflicts.py.
+  // (N = 1024, 2048, both team sizes) or 2-way (N = 512); see tools/lds_conflicts.py.
   static constexpr int LDS_WORDS = N + N / 32;
   RZK_HD static int lds_addr(int j) { return j + (j >> 5); }
-  // phase-2 lane split.  N <= 1024: hi = lane & (E-1), lo = lane >> LE ; N = 2048: hi = lane >> 1.
+  // phase-2 thread split (which thread bits select the LE-bit "hi" digit); chosen per shape for conflict-free LDS:
+  //   one wavefront, N <= 1024: hi = lane & (E-1), lo = lane >> LE ;  N = 2048: hi = lane >> 1, lo = lane & 1
+  //   two wavefronts (N = 2048): hi = (t >> 2) & 15, lo = (t & 3) | (wave << 2)
   static constexpr bool P2_HI_LOW = (LOGN <= 10);
-  RZK_HD static int p2_hi(int lane) { return P2_HI_LOW ? (lane & (E - 1)) : (lane >> LOSH); }
-  RZK_HD static int p2_lo(int lane) { return P2_HI_LOW ? (lane >> LE) : (lane & ((1 << LOSH) - 1)); }
+  RZK_HD static int p2_hi(int lane) {
+    if (LL == 7) return (lane >> 2) & (E - 1);
+    return P2_HI_LOW ? (lane & (E - 1)) : (lane >> LOSH);
+  }
+  RZK_HD static int p2_lo(int lane) {
+    if (LL == 7) return (lane & 3) | ((lane >> 6) << 2);
+    return P2_HI_LOW ? (lane >> LE) : (lane & ((1 << LOSH) - 1));
+  }
   // coefficient index held by (lane, reg) in each phase
-  RZK_HD static int j_p1(int lane, int e) { return e * 64 + lane; }
-  RZK_HD static int j_p2(int lane, int r) { return p2_hi(lane) * 64 + (r << LOSH) + p2_lo(lane); }
+  RZK_HD static int j_p1(int lane, int e) { return e * LANES + lane; }
+  RZK_HD static int j_p2(int lane, int r) { return p2_hi(lane) * LANES + (r << LOSH) + p2_lo(lane); }
   RZK_HD static int j_p3(int lane, int c) { return lane * E + c; }
   // "RZK NTT layout": word offset, inside one N-word residue polynomial in global memory, of the
-  // phase-3 register c of `lane`; groups of 4 registers form one 16-byte coalesced access.
-  RZK_HD static int mem_p3(int lane, int c) { return (c >> 2) * 256 + lane * 4 + (c & 3); }
+  // phase-3 register c of `lane`; groups of 4 registers form one 16-byte coalesced access.  The layout is
+  // defined by the ONE-wavefront geometry of the ring degree (what the resident key and the batched transforms
+  // use); a two-wavefront team addresses the same words through its own (lane, c) -> position map.
+  static constexpr int E64 = N / 64;
+  RZK_HD static int mem_p3(int lane, int c) {
+    const int j = lane * E + c, l64 = j / E64, c64 = j % E64;
+    return (c64 >> 2) * 256 + l64 * 4 + (c64 & 3);
+  }
+  // index, in 16-byte units, of the group g (registers 4g .. 4g+3) of `lane` in that layout
+  RZK_HD static int key4(int lane, int g) { return mem_p3(lane, 4 * g) >> 2; }
+  // ... and in a buffer that only this team's threads read back (parked sums, Garner state lines): any bijection
+  // will do, lane-consecutive 16-byte slots coalesce best
+  RZK_HD static int own4(int lane, int g) { return g * LANES + lane; }
 };
 
 // ---- LDS transpositions -----------------------------------------------------------------------------
 // Every access is written as (per-lane base) + (compile-time offset), so the compiler folds the offset
 // into the DS instruction and needs ONE address register per pattern.  With j = base_j + const and the
 // pad term j >> 5, the split is exact because the lane part and the constant part never carry into
-// each other below bit 5:
-//   phase 1: j = e*64 + lane          -> addr = [lane + (lane>>5)] + e*66
-//   phase 2: j = hi*64 + (r<<LOSH)+lo -> addr = [hi*66 + lo] + (r<<LOSH) + ((r<<LOSH)>>5)     (lo < 2^LOSH)
-//   phase 3: j = lane*E + c           -> addr = [lane*E + ((lane*E)>>5)] + c                  ((lane*E & 31) + c < 32)
-template <int LOGN>
+// each other below bit 5 (W = LANES + LANES/32 is the padded length of one phase-1 row):
+//   phase 1: j = e*LANES + lane          -> addr = [lane + (lane>>5)] + e*W
+//   phase 2: j = hi*LANES + (r<<LOSH)+lo -> addr = [hi*W + lo] + (r<<LOSH) + ((r<<LOSH)>>5)     (lo < 2^LOSH)
+//   phase 3: j = lane*E + c              -> addr = [lane*E + ((lane*E)>>5)] + c                  ((lane*E & 31) + c < 32)
+template <int LOGN, int LL = 6>
 struct LdsMap {
-  using G = Geo<LOGN>;
+  using G = Geo<LOGN, LL>;
+  static constexpr int W = G::LANES + G::LANES / 32;
   RZK_HD static int base_p1(int lane) { return lane + (lane >> 5); }
-  static constexpr int off_p1(int e) { return e * 66; }
-  RZK_HD static int base_p2(int lane) { return G::p2_hi(lane) * 66 + G::p2_lo(lane); }
+  static constexpr int off_p1(int e) { return e * W; }
+  RZK_HD static int base_p2(int lane) { return G::p2_hi(lane) * W + G::p2_lo(lane); }
   static constexpr int off_p2(int r) { return (r << G::LOSH) + ((r << G::LOSH) >> 5); }
   RZK_HD static int base_p3(int lane) { return lane * G::E + ((lane * G::E) >> 5); }
   static constexpr int off_p3(int c) { return c; }
 };
-template <int LOGN>
+template <int LOGN, int LL = 6>
 RZK_HD void lds_put_p1(const uint32_t* x, int lane, uint32_t* lds) {
-  uint32_t* p = lds + LdsMap<LOGN>::base_p1(lane);
+  uint32_t* p = lds + LdsMap<LOGN, LL>::base_p1(lane);
 #pragma unroll
-  for (int e = 0; e < Geo<LOGN>::E; ++e) p[LdsMap<LOGN>::off_p1(e)] = x[e];
+  for (int e = 0; e < Geo<LOGN, LL>::E; ++e) p[LdsMap<LOGN, LL>::off_p1(e)] = x[e];
 }
-template <int LOGN>
+template <int LOGN, int LL = 6>
 RZK_HD void lds_get_p1(uint32_t* x, int lane, const uint32_t* lds) {
-  const uint32_t* p = lds + LdsMap<LOGN>::base_p1(lane);
+  const uint32_t* p = lds + LdsMap<LOGN, LL>::base_p1(lane);
 #pragma unroll
-  for (int e = 0; e < Geo<LOGN>::E; ++e) x[e] = p[LdsMap<LOGN>::off_p1(e)];
+  for (int e = 0; e < Geo<LOGN, LL>::E; ++e) x[e] = p[LdsMap<LOGN, LL>::off_p1(e)];
 }
-template <int LOGN>
+template <int LOGN, int LL = 6>
 RZK_HD void lds_put_p2(const uint32_t* x, int lane, uint32_t* lds) {
-  uint32_t* p = lds + LdsMap<LOGN>::base_p2(lane);
+  uint32_t* p = lds + LdsMap<LOGN, LL>::base_p2(lane);
 #pragma unroll
-  for (int r = 0; r < Geo<LOGN>::E; ++r) p[LdsMap<LOGN>::off_p2(r)] = x[r];
+  for (int r = 0; r < Geo<LOGN, LL>::E; ++r) p[LdsMap<LOGN, LL>::off_p2(r)] = x[r];
 }
-template <int LOGN>
+template <int LOGN, int LL = 6>
 RZK_HD void lds_get_p2(uint32_t* x, int lane, const uint32_t* lds) {
-  const uint32_t* p = lds + LdsMap<LOGN>::base_p2(lane);
+  const uint32_t* p = lds + LdsMap<LOGN, LL>::base_p2(lane);
 #pragma unroll
-  for (int r = 0; r < Geo<LOGN>::E; ++r) x[r] = p[LdsMap<LOGN>::off_p2(r)];
+  for (int r = 0; r < Geo<LOGN, LL>::E; ++r) x[r] = p[LdsMap<LOGN, LL>::off_p2(r)];
 }
-template <int LOGN>
+template <int LOGN, int LL = 6>
 RZK_HD void lds_put_p3(const uint32_t* x, int lane, uint32_t* lds) {
-  uint32_t* p = lds + LdsMap<LOGN>::base_p3(lane);
+  uint32_t* p = lds + LdsMap<LOGN, LL>::base_p3(lane);
 #pragma unroll
-  for (int c = 0; c < Geo<LOGN>::E; ++c) p[LdsMap<LOGN>::off_p3(c)] = x[c];
+  for (int c = 0; c < Geo<LOGN, LL>::E; ++c) p[LdsMap<LOGN, LL>::off_p3(c)] = x[c];
 }
-template <int LOGN>
+template <int LOGN, int LL = 6>
 RZK_HD void lds_get_p3(uint32_t* x, int lane, const uint32_t* lds) {
-  const uint32_t* p = lds + LdsMap<LOGN>::base_p3(lane);
+  const uint32_t* p = lds + LdsMap<LOGN, LL>::base_p3(lane);
 #pragma unroll
-  for (int c = 0; c < Geo<LOGN>::E; ++c) x[c] = p[LdsMap<LOGN>::off_p3(c)];
+  for (int c = 0; c < Geo<LOGN, LL>::E; ++c) x[c] = p[LdsMap<LOGN, LL>::off_p3(c)];
 }
 
 // ---- forward transform, register phases ----------------------------------------------------------------
 // tw: Montgomery-form table, tw[m + i] = psi^{bitrev(m+i)} * R mod p (first N entries used).
-template <int LOGN>
+template <int LOGN, int LL = 6>
 RZK_HD void fwd_phase1(uint32_t* x, const uint32_t* tw, const PrimeConsts& pc) {
-  using G = Geo<LOGN>;
+  using G = Geo<LOGN, LL>;
   int nb = 0;
   (void)nb;
 #pragma unroll
@@ -211,9 +238,9 @@ RZK_HD void fwd_phase1(uint32_t* x, const uint32_t* tw, const PrimeConsts& pc) {
     }
   }
 }
-template <int LOGN>
+template <int LOGN, int LL = 6>
 RZK_HD void fwd_phase2(uint32_t* x, int lane, const uint32_t* tw, const PrimeConsts& pc) {
-  using G = Geo<LOGN>;
+  using G = Geo<LOGN, LL>;
   int nb = 0;
   (void)nb;
   const int hi = G::p2_hi(lane);
@@ -230,9 +257,9 @@ RZK_HD void fwd_phase2(uint32_t* x, int lane, const uint32_t* tw, const PrimeCon
     }
   }
 }
-template <int LOGN>
+template <int LOGN, int LL = 6>
 RZK_HD void fwd_phase3(uint32_t* x, int lane, const uint32_t* tw, const PrimeConsts& pc) {
-  using G = Geo<LOGN>;
+  using G = Geo<LOGN, LL>;
   int nb = 0;
   (void)nb;
 #pragma unroll
@@ -251,9 +278,9 @@ RZK_HD void fwd_phase3(uint32_t* x, int lane, const uint32_t* tw, const PrimeCon
 }
 
 // ---- inverse transform, register phases (mirror image; tw = psi^{-bitrev} * R) -------------------------------
-template <int LOGN>
+template <int LOGN, int LL = 6>
 RZK_HD void inv_phase3(uint32_t* x, int lane, const uint32_t* tw, const PrimeConsts& pc) {
-  using G = Geo<LOGN>;
+  using G = Geo<LOGN, LL>;
   int nb = 0;
   (void)nb;
 #pragma unroll
@@ -270,9 +297,9 @@ RZK_HD void inv_phase3(uint32_t* x, int lane, const uint32_t* tw, const PrimeCon
     }
   }
 }
-template <int LOGN>
+template <int LOGN, int LL = 6>
 RZK_HD void inv_phase2(uint32_t* x, int lane, const uint32_t* tw, const PrimeConsts& pc) {
-  using G = Geo<LOGN>;
+  using G = Geo<LOGN, LL>;
   int nb = 0;
   (void)nb;
   const int hi = G::p2_hi(lane);
@@ -289,9 +316,9 @@ RZK_HD void inv_phase2(uint32_t* x, int lane, const uint32_t* tw, const PrimeCon
     }
   }
 }
-template <int LOGN>
+template <int LOGN, int LL = 6>
 RZK_HD void inv_phase1(uint32_t* x, const uint32_t* tw, const PrimeConsts& pc) {
-  using G = Geo<LOGN>;
+  using G = Geo<LOGN, LL>;
   int nb = 0;
   (void)nb;
 #pragma unroll

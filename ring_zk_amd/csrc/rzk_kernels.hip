@@ -24,38 +24,6 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int LOGN>
-__device__ __forceinline__ void wave_fwd(uint32_t* x, int lane, uint32_t* lds, const uint32_t* __restrict__ tw,
-                                         const PrimeConsts& pc) {
-  fwd_phase1<LOGN>(x, tw, pc);
-  lds_put_p1<LOGN>(x, lane, lds);
-  wave_sync();
-  lds_get_p2<LOGN>(x, lane, lds);
-  wave_sync();
-  fwd_phase2<LOGN>(x, lane, tw, pc);
-  lds_put_p2<LOGN>(x, lane, lds);
-  wave_sync();
-  lds_get_p3<LOGN>(x, lane, lds);
-  wave_sync();
-  fwd_phase3<LOGN>(x, lane, tw, pc);
-}
-
-template <int LOGN>
-__device__ __forceinline__ void wave_inv(uint32_t* x, int lane, uint32_t* lds, const uint32_t* __restrict__ tw,
-                                         const PrimeConsts& pc) {
-  inv_phase3<LOGN>(x, lane, tw, pc);
-  lds_put_p3<LOGN>(x, lane, lds);
-  wave_sync();
-  lds_get_p2<LOGN>(x, lane, lds);
-  wave_sync();
-  inv_phase2<LOGN>(x, lane, tw, pc);
-  lds_put_p2<LOGN>(x, lane, lds);
-  wave_sync();
-  lds_get_p1<LOGN>(x, lane, lds);
-  wave_sync();
-  inv_phase1<LOGN>(x, tw, pc);
-}
-
 // ---- wave reductions ------------------------------------------------------------------------------------
 // Butterfly inside the 16-lane rows with DPP operand modifiers (xor 1, xor 2, half-row mirror, row mirror), then the
 // two row broadcasts of GFX9 (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3): six VALU instructions
@@ -123,22 +91,23 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 // total is within a factor (1 +- 2^-18) of S.  kNormSlack = 2^-17 covers that with room.
 //   * prime count: S_up = S_float * (1 + kNormSlack) >= S; the bound only has to be safe, never tight.
 //   * norm predicate (Params::check_*_constraint, sum c^2 < L with L <= 2^48): decided by the float total whenever
-//     it is outside [L (1 - slack), L (1 + slack)], and by exact integer arithmetic (sum_sq_exact) inside, so the
+//     it is outside [L (1 - slack), L (1 + slack)], and by exact integer arithmetic (lane_sum_sq_exact) inside, so the
 //     verdict is exact for every input: the boundary cases of the tests (flip exactly at (bound+1)^2) take that path.
 constexpr float kNormSlack = 0x1p-17f;
 template <int E>
-__device__ __forceinline__ float sum_sq_f32(const int32_t* v) {   // wave-uniform float total of sum v^2
+__device__ __forceinline__ float lane_sum_sq_f32(const int32_t* v) {   // this lane's share of sum v^2
   float ss = 0.f;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const float f = (float)v[e];
     ss = __builtin_fmaf(f, f, ss);
   }
-  return wave_sum_f32(ss);
+  return ss;
 }
-// exact sum over the wave of min(|v|, 2^24)^2, saturated at 2^48 per lane: equals sum v^2 whenever that is below 2^48
+// this lane's share of the exact sum of min(|v|, 2^24)^2, saturated at 2^48: the team total equals sum v^2 whenever
+// that is below 2^48
 template <int E>
-__device__ __forceinline__ uint64_t sum_sq_exact(const int32_t* v) {
+__device__ __forceinline__ uint64_t lane_sum_sq_exact(const int32_t* v) {
   uint64_t sq = 0;
 #pragma unroll
   for (int e = 0; e < E; ++e) {
@@ -147,22 +116,146 @@ __device__ __forceinline__ uint64_t sum_sq_exact(const int32_t* v) {
     a = a < (1u << 24) ? a : (1u << 24);
     sq += (uint64_t)a * a;
   }
-  sq = sq < (1ull << 48) ? sq : (1ull << 48);
-  return wave_sum_u56(sq);
-}
-// sum v^2 < limit ?  (limit <= 2^48; ss = sum_sq_f32 of the same registers)
-template <int E>
-__device__ __forceinline__ bool norm_below(const int32_t* v, float ss, uint64_t limit) {
-  const double s = (double)ss, lim = (double)limit;
-  if (s * (1.0 + 2.0 * (double)kNormSlack) < lim) return true;
-  if (s * (1.0 - 2.0 * (double)kNormSlack) >= lim) return false;
-  return sum_sq_exact<E>(v) < limit;
+  return sq < (1ull << 48) ? sq : (1ull << 48);
 }
 // Wave-uniform floats are kept in scalar registers: the bounds below live through whole prime passes, where every
 // vector register counts (gfx9 has no scalar float ALU, so the arithmetic itself runs on the VALU; v_readfirstlane
 // brings the result back).
 __device__ __forceinline__ float uniform_f32(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+
+// ---- teams ------------------------------------------------------------------------------------------------------
+// Who transforms one polynomial together (Geo<LOGN, LL>, rzk_core.h) and how its threads meet:
+//   WaveTeam  one wavefront: the lanes run in lockstep, a "barrier" only stops the compiler from moving LDS accesses
+//             across a phase boundary (wave_sync); sums are DPP reductions.
+//   PairTeam  two wavefronts that ARE the workgroup (128 threads, N = 2048): s_barrier at the phase boundaries; a
+//             sum is two wave reductions exchanged through two LDS words, added in the same order by both waves, so
+//             that both take bit-identical decisions (prime counts, exact-path switches) and never part ways
+//             before a barrier.
+struct WaveTeam {
+  static constexpr int LL = 6;
+  static constexpr int kTeamsPerBlock = 4;
+  __device__ __forceinline__ static void sync() { wave_sync(); }
+  __device__ __forceinline__ static float sum_f32(float v) { return wave_sum_f32(v); }
+  __device__ __forceinline__ static uint64_t sum_u56(uint64_t v) { return wave_sum_u56(v); }
+};
+struct PairTeam {
+  static constexpr int LL = 7;
+  static constexpr int kTeamsPerBlock = 1;
+  __device__ __forceinline__ static void sync() { __syncthreads(); }
+  __device__ __forceinline__ static float sum_f32(float v) {
+    __shared__ float xf[2];
+    const float w = wave_sum_f32(v);
+    if ((threadIdx.x & 63) == 0) xf[(threadIdx.x >> 6) & 1] = w;
+    __syncthreads();
+    const float tot = xf[0] + xf[1];
+    __syncthreads();   // the words are free again
+    return uniform_f32(tot);
+  }
+  __device__ __forceinline__ static uint64_t sum_u56(uint64_t v) {
+    __shared__ uint64_t xq[2];
+    const uint64_t w = wave_sum_u56(v);
+    if ((threadIdx.x & 63) == 0) xq[(threadIdx.x >> 6) & 1] = w;
+    __syncthreads();
+    const uint64_t tot = xq[0] + xq[1];
+    __syncthreads();
+    return tot;
+  }
+};
+
+// BlockPairTeam: two-wavefront teams INSIDE a larger workgroup (row_block_kernel at N = 2048: eight pairs around the
+// staged operand transforms).  s_barrier would stop all sixteen waves, so a pair meets through an LDS word of its own:
+// the first lane of each wave adds 1 and learns from the returned value which meeting this is — an even old value
+// means "I am first": wait until the word has passed old + 2; odd means the partner is already there.  The word only
+// grows, so no per-wave generation state is needed; the LDS unit executes one wavefront's instructions in order, so the
+// arrive is behind that wave's slab writes and the poll in front of its slab reads (release / acquire at workgroup
+// scope keep the compiler honest about it).  The words are cleared once per workgroup (init).
+struct BlockPairTeam {
+  static constexpr int LL = 7;
+  static constexpr int kMaxPairs = 8;
+  __device__ __forceinline__ static uint32_t* words() {
+    __shared__ uint32_t w[kMaxPairs * 4];   // per pair: meeting counter, pad, two exchange words
+    return w + ((threadIdx.x >> 7) & (kMaxPairs - 1)) * 4;
+  }
+  __device__ __forceinline__ static void init() {
+    if ((threadIdx.x & 127) == 0) words()[0] = 0;
+    __syncthreads();
+  }
+  __device__ __forceinline__ static void sync() {
+    uint32_t* c = words();
+    uint32_t old = 0;
+    if ((threadIdx.x & 63) == 0) old = __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+    const uint32_t target = (old | 1u) + 1u;
+    while ((int32_t)(__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - target) < 0) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+  __device__ __forceinline__ static float sum_f32(float v) {
+    float* xf = reinterpret_cast<float*>(words() + 2);
+    const float w = wave_sum_f32(v);
+    if ((threadIdx.x & 63) == 0) xf[(threadIdx.x >> 6) & 1] = w;
+    sync();
+    const float tot = xf[0] + xf[1];
+    sync();   // the words are free again
+    return uniform_f32(tot);
+  }
+  __device__ __forceinline__ static uint64_t sum_u56(uint64_t v) {   // (rare path: two 28-bit halves through the two words)
+    const uint64_t w = wave_sum_u56(v);
+    uint32_t* xw = words() + 2;
+    uint64_t tot = 0;
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      if ((threadIdx.x & 63) == 0) xw[(threadIdx.x >> 6) & 1] = (uint32_t)(w >> (28 * h)) & 0xfffffffu;
+      sync();
+      tot += ((uint64_t)xw[0] + xw[1]) << (28 * h);
+      sync();
+    }
+    return tot;
+  }
+};
+
+template <int LOGN, class TM = WaveTeam>
+__device__ __forceinline__ void wave_fwd(uint32_t* x, int lane, uint32_t* lds, const uint32_t* __restrict__ tw,
+                                         const PrimeConsts& pc) {
+  constexpr int LL = TM::LL;
+  fwd_phase1<LOGN, LL>(x, tw, pc);
+  lds_put_p1<LOGN, LL>(x, lane, lds);
+  TM::sync();
+  lds_get_p2<LOGN, LL>(x, lane, lds);
+  TM::sync();
+  fwd_phase2<LOGN, LL>(x, lane, tw, pc);
+  lds_put_p2<LOGN, LL>(x, lane, lds);
+  TM::sync();
+  lds_get_p3<LOGN, LL>(x, lane, lds);
+  TM::sync();
+  fwd_phase3<LOGN, LL>(x, lane, tw, pc);
+}
+
+template <int LOGN, class TM = WaveTeam>
+__device__ __forceinline__ void wave_inv(uint32_t* x, int lane, uint32_t* lds, const uint32_t* __restrict__ tw,
+                                         const PrimeConsts& pc) {
+  constexpr int LL = TM::LL;
+  inv_phase3<LOGN, LL>(x, lane, tw, pc);
+  lds_put_p3<LOGN, LL>(x, lane, lds);
+  TM::sync();
+  lds_get_p2<LOGN, LL>(x, lane, lds);
+  TM::sync();
+  inv_phase2<LOGN, LL>(x, lane, tw, pc);
+  lds_put_p2<LOGN, LL>(x, lane, lds);
+  TM::sync();
+  lds_get_p1<LOGN, LL>(x, lane, lds);
+  TM::sync();
+  inv_phase1<LOGN, LL>(x, tw, pc);
+}
+
+// sum v^2 < limit ?  (limit <= 2^48; ss = the team's float total of the same registers)
+template <int E, class TM = WaveTeam>
+__device__ __forceinline__ bool norm_below(const int32_t* v, float ss, uint64_t limit) {
+  const double s = (double)ss, lim = (double)limit;
+  if (s * (1.0 + 2.0 * (double)kNormSlack) < lim) return true;
+  if (s * (1.0 - 2.0 * (double)kNormSlack) >= lim) return false;
+  return TM::sum_u56(lane_sum_sq_exact<E>(v)) < limit;
 }
 // upper bound of |.|_2 from the float total
 __device__ __forceinline__ float norm2_upper(float ss) {
@@ -216,7 +309,7 @@ __device__ __forceinline__ bool canon_fail(uint32_t bad, uint32_t mx, uint32_t q
 }
 // A non-canonical coefficient was loaded for proof `bo`: clear its verdict (all bits) and raise the sticky word.
 __device__ __forceinline__ void input_fault(const Operands& ops, uint8_t* flags, uint32_t bo, int lane) {
-  if (lane != 0) return;
+  if ((lane & 63) != 0) return;   // the first lane of the wavefront that saw the fault (teams of two report per wave)
   if (flags) {
     if (ops.pad) {
       const uintptr_t a = reinterpret_cast<uintptr_t>(flags + bo);
@@ -256,31 +349,53 @@ __device__ __forceinline__ const int64_t* operand_ptr(const Operands& ops, uint3
 // measure (the first prime pass): nrm2 = an upper bound of the polynomial's 2-norm (wave-uniform), and — check — the
 // fused norm predicate sum c^2 < limit, exact (norm_below); unless `trusted`, the same pass proves that every
 // coefficient is canonical (canon_lo_mx).  Later passes re-read the low words only.
-template <int LOGN>
+template <int LOGN, class TM = WaveTeam>
 __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict__ src, int lane, const PrimeConsts& pc,
                                           bool measure, float& nrm2, bool check, uint64_t limit, bool& below,
                                           uint32_t qhalf, bool trusted, bool& fault) {
-  using G = Geo<LOGN>;
-  int32_t v[G::E];
+  using G = Geo<LOGN, TM::LL>;
   if (measure) {
+    // one pass: the 64-bit coefficient is tested, squared into the float sum and lifted as soon as it arrives, so that
+    // only the lifted residues stay in registers (no second copy of the polynomial)
+    float part = 0.f;
     if (trusted) {
 #pragma unroll
-      for (int e = 0; e < G::E; ++e) v[e] = (int32_t)src[G::j_p1(lane, e)];
+      for (int e = 0; e < G::E; ++e) {
+        const int32_t v = (int32_t)src[G::j_p1(lane, e)];
+        const float f = (float)v;
+        part = __builtin_fmaf(f, f, part);
+        x[e] = lift(v, pc);
+      }
     } else {
       uint32_t bad = 0, mx = 0;
 #pragma unroll
-      for (int e = 0; e < G::E; ++e) v[e] = canon_lo_mx(src[G::j_p1(lane, e)], qhalf, bad, mx);
+      for (int e = 0; e < G::E; ++e) {
+        const int32_t v = canon_lo_mx(src[G::j_p1(lane, e)], qhalf, bad, mx);
+        const float f = (float)v;
+        part = __builtin_fmaf(f, f, part);
+        x[e] = lift(v, pc);
+      }
       fault = fault || canon_fail(bad, mx, qhalf);
     }
-    const float ss = sum_sq_f32<G::E>(v);
+    const float ss = TM::sum_f32(part);
     nrm2 = norm2_upper(ss);
-    if (check) below = norm_below<G::E>(v, ss, limit);
+    if (check) {
+      const double sd = (double)ss, lim = (double)limit;
+      if (sd * (1.0 + 2.0 * (double)kNormSlack) < lim) {
+        below = true;
+      } else if (sd * (1.0 - 2.0 * (double)kNormSlack) >= lim) {
+        below = false;
+      } else {   // inside the rounding band of the limit: exact integers, from the lifted residues (v = x - 2p)
+        int32_t v[G::E];
+#pragma unroll
+        for (int e = 0; e < G::E; ++e) v[e] = (int32_t)(x[e] - pc.twop);
+        below = TM::sum_u56(lane_sum_sq_exact<G::E>(v)) < limit;
+      }
+    }
   } else {
 #pragma unroll
-    for (int e = 0; e < G::E; ++e) v[e] = (int32_t)src[G::j_p1(lane, e)];
+    for (int e = 0; e < G::E; ++e) x[e] = lift((int32_t)src[G::j_p1(lane, e)], pc);
   }
-#pragma unroll
-  for (int e = 0; e < G::E; ++e) x[e] = lift(v[e], pc);
 }
 
 // =============================================================================================
@@ -475,13 +590,13 @@ __device__ __forceinline__ void shift_product(uint32_t* res, bool fresh, bool mi
 }
 
 // acc +/- (term) for prime `pi`, transforming the term's operands in the wave.
-template <int LOGN, bool HAS_VEC, bool OPQ = false>
+template <int LOGN, bool HAS_VEC, bool OPQ = false, class TM = WaveTeam>
 __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const Operands& ops, uint32_t b,
                                             uint32_t bo, int lane, uint32_t* lds, const uint32_t* __restrict__ twf,
                                             const PrimeConsts& pc, int pi, const uint32_t* __restrict__ key_ntt,
                                             const double* __restrict__ key_l2, bool first, float& bound,
                                             uint8_t* __restrict__ flags, uint32_t qhalf) {
-  using G = Geo<LOGN>;
+  using G = Geo<LOGN, TM::LL>;
   constexpr int E = G::E;
   constexpr int N = G::N;
   // optional opaque copy of the lane id (RZK_OPAQUE): stops hoisting of lane-dependent addresses
@@ -492,9 +607,9 @@ __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const 
   bool below = true, fault = false;
   const bool chk = first && (tm.kind & (TERM_CHECK | TERM_CHECK2));
   const bool trusted = ops.trusted != 0;
-  load_lift<LOGN>(x, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), ln, pc, first, nb, chk, ops.norm_limit, below, qhalf, trusted, fault);
-  if (chk && !below && lane == 0) fail_check(flags + bo, ops.pad != 0, (tm.kind & TERM_CHECK2) != 0);
-  wave_fwd<LOGN>(x, ln, lds, twf, pc);
+  load_lift<LOGN, TM>(x, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), ln, pc, first, nb, chk, ops.norm_limit, below, qhalf, trusted, fault);
+  if (chk && !below && (lane & 63) == 0) fail_check(flags + bo, ops.pad != 0, (tm.kind & TERM_CHECK2) != 0);
+  wave_fwd<LOGN, TM>(x, ln, lds, twf, pc);
   if (HAS_VEC && (tm.kind & TERM_KIND_MASK) == TERM_VEC) {
     // product of two per-proof polynomials: fold N^-1 and the Montgomery factor into one of them
     uint32_t xb[E];
@@ -502,8 +617,8 @@ __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const 
     for (int c = 0; c < E; ++c) xb[c] = csub(mont_lazy(x[c], pc.ninv_r2, pc.p, pc.npinv), pc.p);
     float na = 0.f;
     bool unused_below = true;
-    load_lift<LOGN>(x, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), ln, pc, first, na, false, 0, unused_below, qhalf, trusted, fault);
-    wave_fwd<LOGN>(x, ln, lds, twf, pc);
+    load_lift<LOGN, TM>(x, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), ln, pc, first, na, false, 0, unused_below, qhalf, trusted, fault);
+    wave_fwd<LOGN, TM>(x, ln, lds, twf, pc);
     if (first) bound = bound_fma(na, nb, bound);   // |a (*) b|_inf <= |a|_2 |b|_2
     if (tm.sign >= 0) {
 #pragma unroll
@@ -518,7 +633,7 @@ __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const 
     if (tm.sign >= 0) {
 #pragma unroll
       for (int g = 0; g < E / 4; ++g) {
-        const uint4 kv = kp[g * 64 + ln];
+        const uint4 kv = kp[G::key4(ln, g)];
         acc[4 * g + 0] = mac_add(acc[4 * g + 0], x[4 * g + 0], kv.x, pc);
         acc[4 * g + 1] = mac_add(acc[4 * g + 1], x[4 * g + 1], kv.y, pc);
         acc[4 * g + 2] = mac_add(acc[4 * g + 2], x[4 * g + 2], kv.z, pc);
@@ -527,7 +642,7 @@ __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const 
     } else {
 #pragma unroll
       for (int g = 0; g < E / 4; ++g) {
-        const uint4 kv = kp[g * 64 + ln];
+        const uint4 kv = kp[G::key4(ln, g)];
         acc[4 * g + 0] = mac_sub(acc[4 * g + 0], x[4 * g + 0], kv.x, pc);
         acc[4 * g + 1] = mac_sub(acc[4 * g + 1], x[4 * g + 1], kv.y, pc);
         acc[4 * g + 2] = mac_sub(acc[4 * g + 2], x[4 * g + 2], kv.z, pc);
@@ -540,15 +655,15 @@ __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const 
 
 // inverse transform of the prime-`pi` accumulator and fold into the Garner state: word A in LDS, word B
 // (third prime only) in the per-wave global scratch line.  acc is clobbered.
-template <int LOGN, bool OPQ = false>
+template <int LOGN, bool OPQ = false, class TM = WaveTeam>
 __device__ __forceinline__ void inverse_and_fold(int pi, int np, uint32_t* acc, int lane, uint32_t* lds,
                                                  const uint32_t* __restrict__ twi, const PrimeConsts& pc,
                                                  uint32_t* st_lds, uint32_t* __restrict__ st_glb, const DevTables& T) {
-  using G = Geo<LOGN>;
+  using G = Geo<LOGN, TM::LL>;
   constexpr int E = G::E;
   int li = lane;
   RZK_OPAQUE(li);
-  wave_inv<LOGN>(acc, li, lds, twi, pc);
+  wave_inv<LOGN, TM>(acc, li, lds, twi, pc);
   if (pi == 0) {
 #pragma unroll
     for (int e = 0; e < E; ++e) st_lds[G::j_p1(li, e)] = crt_fold0(acc[e], np, T.pc, T.crt);
@@ -579,11 +694,11 @@ __device__ __forceinline__ void inverse_and_fold(int pi, int np, uint32_t* acc, 
 // fused norm predicate sum c^2 < limit of the polynomial an addition loads.  The epilogues accumulate the float sum
 // of squares per marked addition while they load it; the verdict is taken here, exactly (see "norms" above: float
 // total outside the rounding band of the limit, otherwise the polynomial is re-read and summed in integers).
-template <int LOGN>
+template <int LOGN, class TM = WaveTeam>
 __device__ __forceinline__ void checked_add_verdicts(const Program* __restrict__ prog, const Row row, const Operands& ops,
                                                      uint32_t b, uint32_t bo, int lane, const float* add_ss,
                                                      uint8_t* __restrict__ flags) {
-  using G = Geo<LOGN>;
+  using G = Geo<LOGN, TM::LL>;
 #pragma unroll 1
   for (uint32_t a = 0; a < row.nadds && a < 4; ++a) {
     const AddTerm ad = table_load(&prog->adds[row.add0 + a]);
@@ -591,7 +706,7 @@ __device__ __forceinline__ void checked_add_verdicts(const Program* __restrict__
     float part = 0.f;
 #pragma unroll
     for (int sl = 0; sl < 4; ++sl) part = (sl == (int)a) ? add_ss[sl] : part;
-    const double sfl = (double)wave_sum_f32(part), lim = (double)ops.norm_limit;
+    const double sfl = (double)TM::sum_f32(part), lim = (double)ops.norm_limit;
     bool below;
     if (sfl * (1.0 + 2.0 * (double)kNormSlack) < lim) {
       below = true;
@@ -602,19 +717,19 @@ __device__ __forceinline__ void checked_add_verdicts(const Program* __restrict__
       int32_t v[G::E];
 #pragma unroll
       for (int e = 0; e < G::E; ++e) v[e] = (int32_t)src[G::j_p1(lane, e)];
-      below = sum_sq_exact<G::E>(v) < ops.norm_limit;
+      below = TM::sum_u56(lane_sum_sq_exact<G::E>(v)) < ops.norm_limit;
     }
-    if (!below && lane == 0) fail_check(flags + bo, ops.pad != 0, (ad.op & ADD_CHECK2) != 0);
+    if (!below && (lane & 63) == 0) fail_check(flags + bo, ops.pad != 0, (ad.op & ADD_CHECK2) != 0);
   }
 }
 
 // One chunk of one plain addition: u[i] +/-= operand coefficient (j_p1(lane, e0 + i)) in 32-bit arithmetic mod q;
 // canonical test unless trusted; float sum of squares into add_ss[slot] for checked additions.
-template <int LOGN, int CH>
+template <int LOGN, int CH, class TM = WaveTeam>
 __device__ __forceinline__ void add_chunk(uint32_t* u, const AddTerm ad, uint32_t a, const int64_t* __restrict__ src, int lane,
                                           int e0, uint32_t q, uint32_t qhalf, bool trusted, uint32_t& in_bad, uint32_t& in_mx,
                                           float* add_ss) {
-  using G = Geo<LOGN>;
+  using G = Geo<LOGN, TM::LL>;
   int32_t av[CH];
   if (trusted) {
 #pragma unroll
@@ -645,12 +760,12 @@ __device__ __forceinline__ void add_chunk(uint32_t* u, const AddTerm ad, uint32_
 
 // plain additions in 32-bit arithmetic mod q, then centre and store / zero test; RZK_EPI_CHUNK coefficients
 // per lane at a time.  Checked additions also evaluate the fused norm predicate.
-template <int LOGN>
+template <int LOGN, class TM = WaveTeam>
 __device__ __forceinline__ void row_epilogue(const Program* __restrict__ prog, const Row row, const Operands& ops,
                                              uint32_t b, uint32_t bo, int lane, bool has_terms, int np,
                                              const uint32_t* st_lds, const DevTables& T, uint8_t* __restrict__ flags,
                                              const uint32_t* __restrict__ st_sh = nullptr) {
-  using G = Geo<LOGN>;
+  using G = Geo<LOGN, TM::LL>;
   constexpr int E = G::E;
   constexpr int N = G::N;
   int nz = 0;
@@ -676,7 +791,7 @@ __device__ __forceinline__ void row_epilogue(const Program* __restrict__ prog, c
 #pragma unroll 1
     for (uint32_t a = 0; a < row.nadds; ++a) {
       const AddTerm ad = table_load(&prog->adds[row.add0 + a]);
-      add_chunk<LOGN, CH>(u, ad, a, operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, N), lane, e0, q, T.crt.qhalf, trusted,
+      add_chunk<LOGN, CH, TM>(u, ad, a, operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, N), lane, e0, q, T.crt.qhalf, trusted,
                           in_bad, in_mx, add_ss);
     }
     if (row.mode == MODE_STORE) {
@@ -689,10 +804,10 @@ __device__ __forceinline__ void row_epilogue(const Program* __restrict__ prog, c
     }
   }
   if (row.mode != MODE_STORE) {
-    if (__any(nz) && lane == 0) flags[bo] = 0;
+    if (__any(nz) && (lane & 63) == 0) flags[bo] = 0;
   }
   if (row.nadds && !trusted && canon_fail(in_bad, in_mx, T.crt.qhalf)) input_fault(ops, flags, bo, lane);
-  if (ops.norm_limit) checked_add_verdicts<LOGN>(prog, row, ops, b, bo, lane, add_ss, flags);
+  if (ops.norm_limit) checked_add_verdicts<LOGN, TM>(prog, row, ops, b, bo, lane, add_ss, flags);
 }
 
 __device__ __forceinline__ int primes_for(float fbound, const DevTables& T) {
@@ -763,10 +878,11 @@ __device__ __forceinline__ void set_progress_priority(uint32_t done, uint32_t to
 }
 // x (transform, phase-3 register order) times `mul` (a resident key entry or a second transform, in registers), into
 // row A's accumulator.  init: nothing accumulated yet; to_regs: the unit's last item -> the sum replaces x, else -> P
-template <int LOGN, bool to_regs, bool MINUS>
+template <int LOGN, bool to_regs, bool MINUS, class TM = WaveTeam>
 __device__ __forceinline__ void mac_park_signed(uint32_t* x, const uint32_t* mul, uint4* P4, int lane, bool init,
                                                 const PrimeConsts& pc) {
-  constexpr int E = Geo<LOGN>::E;
+  using G = Geo<LOGN, TM::LL>;
+  constexpr int E = G::E;
   if (init && !MINUS) {   // first product of a sum: the lazy product IS the sum ([0,2p)), no add and no conditional subtract
 #pragma unroll
     for (int g = 0; g < E / 4; ++g) {
@@ -777,7 +893,7 @@ __device__ __forceinline__ void mac_park_signed(uint32_t* x, const uint32_t* mul
 #pragma unroll
         for (int i = 0; i < 4; ++i) x[4 * g + i] = as[i];
       } else {
-        P4[g * 64 + lane] = make_uint4(as[0], as[1], as[2], as[3]);
+        P4[G::own4(lane, g)] = make_uint4(as[0], as[1], as[2], as[3]);
       }
     }
     return;
@@ -785,7 +901,7 @@ __device__ __forceinline__ void mac_park_signed(uint32_t* x, const uint32_t* mul
 #pragma unroll
   for (int g = 0; g < E / 4; ++g) {
     uint4 a = make_uint4(0, 0, 0, 0);
-    if (!init) a = P4[g * 64 + lane];
+    if (!init) a = P4[G::own4(lane, g)];
     uint32_t as[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -794,28 +910,28 @@ __device__ __forceinline__ void mac_park_signed(uint32_t* x, const uint32_t* mul
 #pragma unroll
       for (int i = 0; i < 4; ++i) x[4 * g + i] = as[i];
     } else {
-      P4[g * 64 + lane] = make_uint4(as[0], as[1], as[2], as[3]);
+      P4[G::own4(lane, g)] = make_uint4(as[0], as[1], as[2], as[3]);
     }
   }
 }
 // (the sign is tested once, outside the element loops: a per-element select of mac_add / mac_sub made the compiler
 // branch per coefficient; `mul` must be a register array of the caller, never a pointer chosen at run time, or both
 // candidates end up in scratch memory)
-template <int LOGN, bool to_regs>
+template <int LOGN, bool to_regs, class TM = WaveTeam>
 __device__ __forceinline__ void mac_park(uint32_t* x, const uint32_t* mul, bool minus, uint4* P4, int lane, bool init,
                                          const PrimeConsts& pc) {
-  if (minus) mac_park_signed<LOGN, to_regs, true>(x, mul, P4, lane, init, pc);
-  else mac_park_signed<LOGN, to_regs, false>(x, mul, P4, lane, init, pc);
+  if (minus) mac_park_signed<LOGN, to_regs, true, TM>(x, mul, P4, lane, init, pc);
+  else mac_park_signed<LOGN, to_regs, false, TM>(x, mul, P4, lane, init, pc);
 }
 
 // Inverse transform of a finished accumulator and Garner step `pi` of `np` against the row's global state lines.
 // Returns true when the row's value is complete: acc[e] then holds X mod q in [0,q) for coefficient e*64 + lane.
-template <int LOGN, bool OPQ>
+template <int LOGN, bool OPQ, class TM = WaveTeam>
 __device__ __forceinline__ bool inverse_fold_global(int pi, int np, uint32_t* acc, int lane, uint32_t* lds,
                                                     const uint32_t* __restrict__ twi, const PrimeConsts& pc,
                                                     uint32_t* __restrict__ stA, uint32_t* __restrict__ stB,
                                                     const DevTables& T) {
-  using G = Geo<LOGN>;
+  using G = Geo<LOGN, TM::LL>;
   constexpr int E = G::E;
   int li = lane;
   RZK_OPAQUE(li);
@@ -823,24 +939,24 @@ __device__ __forceinline__ bool inverse_fold_global(int pi, int np, uint32_t* ac
   uint4* __restrict__ B4 = reinterpret_cast<uint4*>(stB);
   // the state words this step needs are requested before the transform, which hides their latency
   // (N <= 1024; at N = 2048 a lane holds 32 coefficients and the registers are not there)
-  constexpr bool EARLY = LOGN <= 10;
+  constexpr bool EARLY = E <= 16;
   uint4 sa[E / 4], sb[E / 4];
   if (EARLY && pi >= 1) {
 #pragma unroll
-    for (int g = 0; g < E / 4; ++g) sa[g] = A4[g * 64 + li];
+    for (int g = 0; g < E / 4; ++g) sa[g] = A4[G::own4(li, g)];
   }
   if (EARLY && pi == 2) {
 #pragma unroll
-    for (int g = 0; g < E / 4; ++g) sb[g] = B4[g * 64 + li];
+    for (int g = 0; g < E / 4; ++g) sb[g] = B4[G::own4(li, g)];
   }
-  wave_inv<LOGN>(acc, li, lds, twi, pc);
+  wave_inv<LOGN, TM>(acc, li, lds, twi, pc);
   if (!EARLY && pi >= 1) {
 #pragma unroll
-    for (int g = 0; g < E / 4; ++g) sa[g] = A4[g * 64 + li];
+    for (int g = 0; g < E / 4; ++g) sa[g] = A4[G::own4(li, g)];
   }
   if (!EARLY && pi == 2) {
 #pragma unroll
-    for (int g = 0; g < E / 4; ++g) sb[g] = B4[g * 64 + li];
+    for (int g = 0; g < E / 4; ++g) sb[g] = B4[G::own4(li, g)];
   }
   if (pi == 0) {
 #pragma unroll
@@ -851,7 +967,7 @@ __device__ __forceinline__ bool inverse_fold_global(int pi, int np, uint32_t* ac
       return true;
     }
 #pragma unroll
-    for (int g = 0; g < E / 4; ++g) A4[g * 64 + li] = make_uint4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+    for (int g = 0; g < E / 4; ++g) A4[G::own4(li, g)] = make_uint4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
     return false;
   }
   if (pi == 1) {
@@ -867,8 +983,8 @@ __device__ __forceinline__ bool inverse_fold_global(int pi, int np, uint32_t* ac
         vb[i] = np == 3 ? crt_value01_modp2(d0[i], d1, T.pc, T.crt) : 0u;
       }
       if (np == 3) {
-        A4[g * 64 + li] = make_uint4(va[0], va[1], va[2], va[3]);
-        B4[g * 64 + li] = make_uint4(vb[0], vb[1], vb[2], vb[3]);
+        A4[G::own4(li, g)] = make_uint4(va[0], va[1], va[2], va[3]);
+        B4[G::own4(li, g)] = make_uint4(vb[0], vb[1], vb[2], vb[3]);
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[4 * g + i] = crt_finish_zq(va[i], 2, T.crt);
@@ -893,11 +1009,11 @@ __device__ __forceinline__ bool inverse_fold_global(int pi, int np, uint32_t* ac
 // u[e] = the row's product sum mod q (coefficient e*64 + lane; zero when the row has no products): adds the sum of
 // the row's rotation terms (st_sh, left in the wave's scratch line by the same lanes), the plain additions, then
 // store / zero test, norm marks of checked additions, canonical-input test of everything loaded.
-template <int LOGN, int CHMAX = 16>
+template <int LOGN, int CHMAX = 16, class TM = WaveTeam>
 __device__ __forceinline__ void finish_row(uint32_t* u, const Program* __restrict__ prog, const Row row,
                                            const Operands& ops, uint32_t b, uint32_t bo, int lane, const DevTables& T,
                                            uint8_t* __restrict__ flags, const uint32_t* __restrict__ st_sh) {
-  using G = Geo<LOGN>;
+  using G = Geo<LOGN, TM::LL>;
   constexpr int E = G::E;
   constexpr int N = G::N;
   const uint32_t q = T.crt.q, qhalf = T.crt.qhalf;
@@ -917,7 +1033,7 @@ __device__ __forceinline__ void finish_row(uint32_t* u, const Program* __restric
 #pragma unroll 1
     for (uint32_t a = 0; a < row.nadds; ++a) {
       const AddTerm ad = table_load(&prog->adds[row.add0 + a]);
-      add_chunk<LOGN, CH>(u + e0, ad, a, operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, N), lane, e0, q, qhalf, trusted,
+      add_chunk<LOGN, CH, TM>(u + e0, ad, a, operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, N), lane, e0, q, qhalf, trusted,
                           in_bad, in_mx, add_ss);
     }
     if (row.mode == MODE_STORE) {
@@ -930,34 +1046,31 @@ __device__ __forceinline__ void finish_row(uint32_t* u, const Program* __restric
     }
   }
   if (row.mode != MODE_STORE) {
-    if (__any(nz) && lane == 0) flags[bo] = 0;
+    if (__any(nz) && (lane & 63) == 0) flags[bo] = 0;
   }
   if (row.nadds && !trusted && canon_fail(in_bad, in_mx, qhalf)) input_fault(ops, flags, bo, lane);
-  if (ops.norm_limit) checked_add_verdicts<LOGN>(prog, row, ops, b, bo, lane, add_ss, flags);
+  if (ops.norm_limit) checked_add_verdicts<LOGN, TM>(prog, row, ops, b, bo, lane, add_ss, flags);
 }
 
-// Wavefronts per workgroup: 4 independent waves (16-wave workgroups whose SIMD mates ranked each other through an LDS
-// table for exact fairness measured slower in round 2 — verify rows 90 vs 81 us — and were removed).
-template <int LOGN>
-struct UnitCfg {
-  static constexpr int WPB = 4;
-};
-
-template <int LOGN, bool HAS_VEC, bool HAS_SHIFT>
-__global__ void __launch_bounds__(64 * UnitCfg<LOGN>::WPB, (LOGN <= 10 && HAS_VEC ? 4 : 1))   // vector x vector variants: hold the 4 waves per SIMD the LDS allows
+// Workgroups: four independent one-wavefront teams (16-wave workgroups whose SIMD mates ranked each other through an LDS
+// table for exact fairness measured slower in round 2 — verify rows 90 vs 81 us — and were removed), or ONE
+// two-wavefront team (PairTeam, N = 2048).  Teams of two are compiled for 4 waves per SIMD (<= 128 VGPRs: 16
+// coefficients per thread, the budget of the N = 1024 kernels).
+template <int LOGN, bool HAS_VEC, bool HAS_SHIFT, class TM = WaveTeam>
+__global__ void __launch_bounds__(TM::kTeamsPerBlock << TM::LL, ((LOGN <= 10 && HAS_VEC) || TM::LL == 7 ? 4 : 1))   // vector x vector variants: hold the 4 waves per SIMD the LDS allows
 unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp, const Operands ops,
             const uint32_t* __restrict__ key_ntt, const double* __restrict__ key_l2, const DevTables* __restrict__ Tp,
             const uint32_t* __restrict__ tw_all, uint32_t* __restrict__ scratch, uint8_t* __restrict__ flags,
             const uint32_t ntasks, const uint32_t units_per_task, const uint32_t tasks_per_entry,
             const uint32_t work_per_task) {
-  using G = Geo<LOGN>;
+  using G = Geo<LOGN, TM::LL>;
   constexpr int E = G::E;
   constexpr int N = G::N;
   constexpr bool OPQ = RZK_UNIT_OPAQUE || LOGN >= RZK_OPAQUE_LANE_MIN_LOGN;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  constexpr int WPB = UnitCfg<LOGN>::WPB;
+  const int lane = threadIdx.x & (G::LANES - 1);                                         // index inside the team
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> TM::LL);           // team of the workgroup
+  constexpr int WPB = TM::kTeamsPerBlock;
   uint32_t* lds = smem + wave * (G::LDS_WORDS + N);             // transposition slab, then P
   uint4* P4 = reinterpret_cast<uint4*>(lds + G::LDS_WORDS);     // G::LDS_WORDS * 4 is a multiple of 16 bytes
   // per-wave global scratch: Garner words [row A | B][word A | B][N], then the sum of row A's rotation terms
@@ -1059,33 +1172,33 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
             const bool chk = first && (im.flags & (TERM_CHECK | TERM_CHECK2));
             {
               RZK_T0();
-              load_lift<LOGN>(x, operand_ptr(ops, im.b_op, im.b_off, b, bo, N), ln, pc, first, nb, chk, ops.norm_limit, below, qhalf,
+              load_lift<LOGN, TM>(x, operand_ptr(ops, im.b_op, im.b_off, b, bo, N), ln, pc, first, nb, chk, ops.norm_limit, below, qhalf,
                               trusted, fault);
               RZK_T1(t_load);
             }
-            if (chk && !below && lane == 0) fail_check(flags + bo, ops.pad != 0, (im.flags & TERM_CHECK2) != 0);
+            if (chk && !below && (lane & 63) == 0) fail_check(flags + bo, ops.pad != 0, (im.flags & TERM_CHECK2) != 0);
             const bool vec = HAS_VEC && im.kind == ITEM_VEC;
             // the resident key entry of row A's product is requested before the transform, which hides its latency
             // (N <= 1024; at N = 2048 the registers are not there and the entry is loaded after the transform)
-            constexpr bool EARLY = LOGN <= 10 && !HAS_VEC;   // (and not next to vector x vector items: their second transform needs the registers)
+            constexpr bool EARLY = E <= 16 && !HAS_VEC;   // (and not next to vector x vector items: their second transform needs the registers)
             uint32_t kreg[E];
             const uint4* __restrict__ kpA = reinterpret_cast<const uint4*>(key_ntt + ((size_t)im.keyA * kKeyImages + pi) * N);
             if (EARLY && !vec && im.keyA != kNoKey) {
 #pragma unroll
               for (int g = 0; g < E / 4; ++g) {
-                const uint4 kv = kpA[g * 64 + ln];
+                const uint4 kv = kpA[G::key4(ln, g)];
                 kreg[4 * g] = kv.x, kreg[4 * g + 1] = kv.y, kreg[4 * g + 2] = kv.z, kreg[4 * g + 3] = kv.w;
               }
             }
             {
               RZK_T0();
-              wave_fwd<LOGN>(x, ln, lds, twf, pc);
+              wave_fwd<LOGN, TM>(x, ln, lds, twf, pc);
               RZK_T1(t_fwd);
             }
             if (!EARLY && !vec && im.keyA != kNoKey) {
 #pragma unroll
               for (int g = 0; g < E / 4; ++g) {
-                const uint4 kv = kpA[g * 64 + ln];
+                const uint4 kv = kpA[G::key4(ln, g)];
                 kreg[4 * g] = kv.x, kreg[4 * g + 1] = kv.y, kreg[4 * g + 2] = kv.z, kreg[4 * g + 3] = kv.w;
               }
             }
@@ -1095,9 +1208,9 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
               for (int c = 0; c < E; ++c) xb[c] = csub(mont_lazy(x[c], pc.ninv_r2, pc.p, pc.npinv), pc.p);
               float na = 0.f;
               bool unused_below = true;
-              load_lift<LOGN>(x, operand_ptr(ops, im.a_op, im.a_off, b, bo, N), ln, pc, first, na, false, 0, unused_below, qhalf,
+              load_lift<LOGN, TM>(x, operand_ptr(ops, im.a_op, im.a_off, b, bo, N), ln, pc, first, na, false, 0, unused_below, qhalf,
                               trusted, fault);
-              wave_fwd<LOGN>(x, ln, lds, twf, pc);
+              wave_fwd<LOGN, TM>(x, ln, lds, twf, pc);
               if (first) boundA = bound_fma(na, nb, boundA);
             } else if (first) {
               if (im.keyA != kNoKey) boundA = bound_fma((float)key_l2[im.keyA], nb, boundA);
@@ -1106,8 +1219,8 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
             const bool feedsA = vec || im.keyA != kNoKey;
             if (!last) {
               RZK_T0();
-              if (vec) mac_park<LOGN, false>(x, xb, im.signA < 0, P4, ln, it == 0, pc);
-              else if (feedsA) mac_park<LOGN, false>(x, kreg, im.signA < 0, P4, ln, it == 0, pc);
+              if (vec) mac_park<LOGN, false, TM>(x, xb, im.signA < 0, P4, ln, it == 0, pc);
+              else if (feedsA) mac_park<LOGN, false, TM>(x, kreg, im.signA < 0, P4, ln, it == 0, pc);
               RZK_T1(t_mac);
               continue;
             }
@@ -1118,13 +1231,13 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
 #pragma unroll
             for (int c = 0; c < E; ++c) acc[c] = x[c];
             if (vec) {
-              mac_park<LOGN, true>(acc, xb, im.signA < 0, P4, ln, it == 0, pc);
+              mac_park<LOGN, true, TM>(acc, xb, im.signA < 0, P4, ln, it == 0, pc);
             } else if (feedsA) {
-              mac_park<LOGN, true>(acc, kreg, im.signA < 0, P4, ln, it == 0, pc);
+              mac_park<LOGN, true, TM>(acc, kreg, im.signA < 0, P4, ln, it == 0, pc);
             } else {   // (an item that only feeds row B)
 #pragma unroll
               for (int g = 0; g < E / 4; ++g) {
-                const uint4 v = P4[g * 64 + ln];
+                const uint4 v = P4[G::own4(ln, g)];
                 acc[4 * g] = v.x, acc[4 * g + 1] = v.y, acc[4 * g + 2] = v.z, acc[4 * g + 3] = v.w;
               }
             }
@@ -1133,10 +1246,10 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
               uint32_t kbr[E];
 #pragma unroll
               for (int g = 0; g < E / 4; ++g) {
-                const uint4 kv = kb[g * 64 + ln];
+                const uint4 kv = kb[G::key4(ln, g)];
                 kbr[4 * g] = kv.x, kbr[4 * g + 1] = kv.y, kbr[4 * g + 2] = kv.z, kbr[4 * g + 3] = kv.w;
               }
-              mac_park<LOGN, false>(x, kbr, im.signB < 0, P4, ln, true, pc);
+              mac_park<LOGN, false, TM>(x, kbr, im.signB < 0, P4, ln, true, pc);
             }
             RZK_T1(t_mac);
           }
@@ -1146,7 +1259,7 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
             if (r == 1) {
 #pragma unroll
               for (int g = 0; g < E / 4; ++g) {
-                const uint4 v = P4[g * 64 + ln];
+                const uint4 v = P4[G::own4(ln, g)];
                 acc[4 * g] = v.x, acc[4 * g + 1] = v.y, acc[4 * g + 2] = v.z, acc[4 * g + 3] = v.w;
               }
             }
@@ -1154,13 +1267,13 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
             RZK_STEP_PRIORITY();
             if (!null_unit) {
               RZK_T0();
-              done = inverse_fold_global<LOGN, OPQ>(pi, np, acc, lane, lds, twf + kTableLen, pc, st + (size_t)(2 * r) * N,
+              done = inverse_fold_global<LOGN, OPQ, TM>(pi, np, acc, lane, lds, twf + kTableLen, pc, st + (size_t)(2 * r) * N,
                                                     st + (size_t)(2 * r + 1) * N, T);
               RZK_T1(t_inv);
             }
             if (done) {
               RZK_T0();
-              finish_row<LOGN>(acc, prog, table_load(&prog->rows[r ? un.rowB : un.rowA]), ops, b, bo, lane, T, flags,
+              finish_row<LOGN, 16, TM>(acc, prog, table_load(&prog->rows[r ? un.rowB : un.rowA]), ops, b, bo, lane, T, flags,
                                (has_shift && r == 0) ? st_sh : nullptr);
               RZK_T1(t_fin);
             }
@@ -1196,23 +1309,24 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
 // unit_kernel's parked sums and global state lines: 1.36 vs 1.85 ms per launch for the Sum rows at (4,9,4), V = 8).
 // Primes one after the other; the first pass measures the operands (prime count, canonical test, norm marks).
 // =============================================================================================
-template <int LOGN, bool HAS_SHIFT>
-__global__ void __launch_bounds__(256, (LOGN <= 10 ? 4 : 1))   // N <= 1024: hold the 4 waves per SIMD the LDS allows
+template <int LOGN, bool HAS_SHIFT, class TM = WaveTeam>
+__global__ void __launch_bounds__(TM::kTeamsPerBlock << TM::LL, (LOGN <= 10 || TM::LL == 7 ? 4 : 1))   // N <= 1024 and teams of two: hold the 4 waves per SIMD the LDS allows
 row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t* __restrict__ key_ntt,
            const double* __restrict__ key_l2, const DevTables* __restrict__ Tp, const uint32_t* __restrict__ tw_all,
            uint32_t* __restrict__ scratch, uint8_t* __restrict__ flags, const uint32_t ntasks) {
-  using G = Geo<LOGN>;
+  using G = Geo<LOGN, TM::LL>;
   constexpr int E = G::E;
   constexpr int N = G::N;
   constexpr bool OPQ = true;   // opaque lane ids: no hoisted address registers
+  constexpr int TPB = TM::kTeamsPerBlock;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // per wave: transposition slab, then Garner word A (one per coefficient); together they also hold the 2N-word
+  const int lane = threadIdx.x & (G::LANES - 1);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> TM::LL);
+  // per team: transposition slab, then Garner word A (one per coefficient); together they also hold the 2N-word
   // image of a rotation term, which is finished before the transforms start
   uint32_t* lds = smem + wave * (G::LDS_WORDS + N);
   uint32_t* st_lds = lds + G::LDS_WORDS;
-  uint32_t* st = scratch + ((size_t)blockIdx.x * 4 + wave) * (size_t)(kScratchLines * N + 16);
+  uint32_t* st = scratch + ((size_t)blockIdx.x * TPB + wave) * (size_t)(kScratchLines * N + 16);
   uint32_t* st_glb = st;            // Garner word B, only touched when a row needs the third prime
   uint32_t* st_sh = st + 4 * N;     // sum of the row's rotation terms mod q
   const DevTables& T = *Tp;
@@ -1220,7 +1334,7 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
   const bool trusted = ops.trusted != 0;
   const uint32_t nrows = prog->nrows;
 
-  for (uint32_t task = blockIdx.x * 4 + wave; task < ntasks; task += gridDim.x * 4) {
+  for (uint32_t task = blockIdx.x * TPB + wave; task < ntasks; task += gridDim.x * TPB) {
     const uint32_t b = task / nrows;
     const uint32_t rowi = task - b * nrows;
     const uint32_t bo = ops.group > 1 ? b / ops.group : b;
@@ -1262,13 +1376,13 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
         for (int c = 0; c < E; ++c) acc[c] = 0;
 #pragma unroll 1
         for (uint32_t t = 0; t < row.nterms; ++t)
-          term_direct<LOGN, true, OPQ>(acc, table_load(&prog->terms[row.term0 + t]), ops, b, bo, lane, lds, twf, pc, pi, key_ntt,
+          term_direct<LOGN, true, OPQ, TM>(acc, table_load(&prog->terms[row.term0 + t]), ops, b, bo, lane, lds, twf, pc, pi, key_ntt,
                                        key_l2, first, bound, flags, qhalf);
         if (first) np = primes_for(bound, T);
-        inverse_and_fold<LOGN, OPQ>(pi, np, acc, lane, lds, twf + kTableLen, pc, st_lds, st_glb, T);
+        inverse_and_fold<LOGN, OPQ, TM>(pi, np, acc, lane, lds, twf + kTableLen, pc, st_lds, st_glb, T);
       }
     }
-    row_epilogue<LOGN>(prog, row, ops, b, bo, lane, has_terms, np, st_lds, T, flags, has_shift ? st_sh : nullptr);
+    row_epilogue<LOGN, TM>(prog, row, ops, b, bo, lane, has_terms, np, st_lds, T, flags, has_shift ? st_sh : nullptr);
   }
 }
 
@@ -1290,7 +1404,8 @@ struct ShiftCfg {   // waves per workgroup: one wave's image is 8 * N bytes of L
   static constexpr int WPB = 4;
 };
 
-template <int LOGN>
+template <int LOGN, bool TRUSTED>   // TRUSTED (Operands::trusted) is a template flag here: as a run-time branch around the loads
+                                    // it changed the compiler's load scheduling (79 instead of 116 VGPRs, 86 us instead of 77)
 __global__ void __launch_bounds__(64 * ShiftCfg<LOGN>::WPB, RZK_SHIFT_MIN_WAVES)
 shift_row_kernel(const Program* __restrict__ prog, const Operands ops, const DevTables* __restrict__ Tp,
                  uint8_t* __restrict__ flags, const uint32_t ntasks) {
@@ -1312,7 +1427,7 @@ shift_row_kernel(const Program* __restrict__ prog, const Operands ops, const Dev
     const uint32_t bo = ops.group > 1 ? b / ops.group : b;
     const Row row = prog->rows[rowi];
     const uint32_t qhalf = T.crt.qhalf;
-    const bool trusted = ops.trusted != 0;
+    constexpr bool trusted = TRUSTED;
     bool fault = false;
     {
       uint32_t res[E];
@@ -1525,18 +1640,19 @@ row_group_kernel(const Program* __restrict__ prog, const Operands ops, const uin
 //            memory); barrier before the next prime overwrites the staged transforms.
 // Every wave runs the same number of barriers: the prime count is the block's maximum, computed by every wave
 // from the same norms in LDS (more primes than a row needs is still exact).
-template <int LOGN>
-__global__ void __launch_bounds__(64 * kBlockWaves)
+template <int LOGN, class TM = WaveTeam>
+__global__ void __launch_bounds__(kBlockWaves << TM::LL)
 row_block_kernel(const Program* __restrict__ prog, const BlockPlan* __restrict__ plan, const Operands ops,
                  const uint32_t* __restrict__ key_ntt, const double* __restrict__ key_l2,
                  const DevTables* __restrict__ Tp, const uint32_t* __restrict__ tw_all, uint32_t* __restrict__ scratch,
                  uint8_t* __restrict__ flags, const uint32_t ntasks) {
-  using G = Geo<LOGN>;
+  using G = Geo<LOGN, TM::LL>;
   constexpr int E = G::E;
   constexpr int N = G::N;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & (G::LANES - 1);                                    // index inside the team
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> TM::LL);      // team of the workgroup (kBlockWaves teams)
+  if constexpr (TM::LL == 7) TM::init();
   uint32_t* staged = smem;                                                     // [kBlockMaxSlots][N]
   uint32_t* lds = smem + kBlockMaxSlots * N + wave * G::LDS_WORDS;             // this wave's transposition slab
   float* norm1 = reinterpret_cast<float*>(smem + kBlockMaxSlots * N + kBlockWaves * G::LDS_WORDS);   // [slots]
@@ -1565,15 +1681,15 @@ row_block_kernel(const Program* __restrict__ prog, const BlockPlan* __restrict__
         bool fault = false;
         int ln = lane;
         asm volatile("" : "+v"(ln));   // opaque lane ids: no lane-dependent addresses kept in registers across the steps
-        load_lift<LOGN>(x, operand_ptr(ops, plan->slot_op[gs], plan->slot_off[gs], b, bo, N), ln, pc, first, nb, chk,
+        load_lift<LOGN, TM>(x, operand_ptr(ops, plan->slot_op[gs], plan->slot_off[gs], b, bo, N), ln, pc, first, nb, chk,
                         ops.norm_limit, below, T.crt.qhalf, ops.trusted != 0, fault);
-        if (chk && !below && lane == 0) flags[bo] = 0;
+        if (chk && !below && (lane & 63) == 0) flags[bo] = 0;
         if (fault) input_fault(ops, flags, bo, lane);
         if (first && lane == 0) norm1[s] = nb;
-        wave_fwd<LOGN>(x, ln, lds, twf, pc);
+        wave_fwd<LOGN, TM>(x, ln, lds, twf, pc);
         uint32_t* dst = staged + s * N + ln;
 #pragma unroll
-        for (int c = 0; c < E; ++c) dst[c * 64] = x[c];
+        for (int c = 0; c < E; ++c) dst[c * G::LANES] = x[c];
       }
       __syncthreads();
       if (first) {
@@ -1607,22 +1723,22 @@ row_block_kernel(const Program* __restrict__ prog, const BlockPlan* __restrict__
           if (tm.sign >= 0) {   // (one wave-uniform branch per term, not a select per coefficient)
 #pragma unroll
             for (int g = 0; g < E / 4; ++g) {
-              const uint4 kv = kp[g * 64 + lm];
+              const uint4 kv = kp[G::key4(lm, g)];
               const uint32_t ks[4] = {kv.x, kv.y, kv.z, kv.w};
 #pragma unroll
-              for (int i = 0; i < 4; ++i) acc[4 * g + i] = mac_add(acc[4 * g + i], xs[(4 * g + i) * 64], ks[i], pc);
+              for (int i = 0; i < 4; ++i) acc[4 * g + i] = mac_add(acc[4 * g + i], xs[(4 * g + i) * G::LANES], ks[i], pc);
             }
           } else {
 #pragma unroll
             for (int g = 0; g < E / 4; ++g) {
-              const uint4 kv = kp[g * 64 + lm];
+              const uint4 kv = kp[G::key4(lm, g)];
               const uint32_t ks[4] = {kv.x, kv.y, kv.z, kv.w};
 #pragma unroll
-              for (int i = 0; i < 4; ++i) acc[4 * g + i] = mac_sub(acc[4 * g + i], xs[(4 * g + i) * 64], ks[i], pc);
+              for (int i = 0; i < 4; ++i) acc[4 * g + i] = mac_sub(acc[4 * g + i], xs[(4 * g + i) * G::LANES], ks[i], pc);
             }
           }
         }
-        inverse_and_fold<LOGN, true>(pi, np, acc, lane, lds, twf + kTableLen, pc, st + (size_t)(2 * r) * N,
+        inverse_and_fold<LOGN, true, TM>(pi, np, acc, lane, lds, twf + kTableLen, pc, st + (size_t)(2 * r) * N,
                                      st + (size_t)(2 * r + 1) * N, T);
       }
       __syncthreads();   // the staged transforms are overwritten by the next prime / next task
@@ -1630,7 +1746,7 @@ row_block_kernel(const Program* __restrict__ prog, const BlockPlan* __restrict__
 #pragma unroll 1
     for (uint32_t r = wave; r < bd.nrows; r += kBlockWaves) {
       const Row row = prog->rows[bd.row0 + r];
-      row_epilogue<LOGN>(prog, row, ops, b, bo, lane, row.nterms > 0, np, st + (size_t)(2 * r) * N, T, flags);
+      row_epilogue<LOGN, TM>(prog, row, ops, b, bo, lane, row.nterms > 0, np, st + (size_t)(2 * r) * N, T, flags);
     }
   }
 }
@@ -1692,7 +1808,7 @@ fwd_slots_kernel(const SlotTable* __restrict__ slots, const Operands ops, const 
       for (int e = 0; e < E; ++e) v[e] = canon_lo_mx(src[G::j_p1(lane, e)], T.crt.qhalf, in_bad, in_mx);
       if (canon_fail(in_bad, in_mx, T.crt.qhalf)) input_fault(ops, flags, bo, lane);
     }
-    const float ss = sum_sq_f32<E>(v);
+    const float ss = wave_sum_f32(lane_sum_sq_f32<E>(v));
     if (lane == 0) {
       norms[((size_t)b * nslots + s) * 2 + 0] = (double)norm2_upper(ss) * (1.0 + 1e-6);   // upper bound of the 2-norm (read back as float)
       norms[((size_t)b * nslots + s) * 2 + 1] = 0.0;
@@ -2300,40 +2416,41 @@ static inline unsigned grid_for(uint64_t tasks, int num_cus, int waves_per_block
 
 size_t row_scratch_words(int logn, int num_cus) { return (size_t)num_cus * 8 * 4 * (((size_t)kScratchLines << logn) + 16); }
 
-template <int LOGN, bool HAS_VEC, bool HAS_SHIFT>
+template <int LOGN, bool HAS_VEC, bool HAS_SHIFT, class TM = WaveTeam>
 static int launch_units_t(const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, const Operands& ops,
                           const uint32_t* d_key_ntt, const double* d_key_l2, const DevTables* T, const uint32_t* d_tw,
                           uint32_t* d_scratch, uint8_t* d_flags, uint32_t ntasks, uint32_t upt, uint32_t tpe, uint32_t wpt) {
-  using G = Geo<LOGN>;
-  constexpr int WPB = UnitCfg<LOGN>::WPB;
-  // per wave: transposition slab + P
-  const size_t lds = WPB * (size_t)(G::LDS_WORDS + G::N) * sizeof(uint32_t);
+  using G = Geo<LOGN, TM::LL>;
+  constexpr int TPB = TM::kTeamsPerBlock;
+  // per team: transposition slab + P
+  const size_t lds = TPB * (size_t)(G::LDS_WORDS + G::N) * sizeof(uint32_t);
   if (lds > 48 * 1024) {   // large dynamic LDS needs an opt-in; per device, so set before every launch (cheap, idempotent)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&unit_kernel<LOGN, HAS_VEC, HAS_SHIFT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&unit_kernel<LOGN, HAS_VEC, HAS_SHIFT, TM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  // scratch sizing: at most num_cus * 32 wave lines; every wave walks its tasks with a grid stride
-  const unsigned grid = grid_for(ntasks, cfg.num_cus, 4, 8);
-  hipLaunchKernelGGL((unit_kernel<LOGN, HAS_VEC, HAS_SHIFT>), dim3(grid), dim3(64 * WPB), lds, (hipStream_t)cfg.stream, d_prog,
-                     d_wp, ops, d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks, upt, tpe, wpt);
+  // scratch sizing: at most num_cus * 32 team lines; every team walks its tasks with a grid stride
+  const unsigned grid = grid_for(ntasks, cfg.num_cus, TPB, 8);
+  hipLaunchKernelGGL((unit_kernel<LOGN, HAS_VEC, HAS_SHIFT, TM>), dim3(grid), dim3(TPB << TM::LL), lds, (hipStream_t)cfg.stream,
+                     d_prog, d_wp, ops, d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks, upt, tpe, wpt);
   RZK_LAUNCH_CHECK();
   return 0;
 }
 
-template <int LOGN, bool HAS_SHIFT>
+template <int LOGN, bool HAS_SHIFT, class TM = WaveTeam>
 static int launch_rows_t(const LaunchCfg& cfg, const Program* d_prog, const Operands& ops, const uint32_t* d_key_ntt,
                          const double* d_key_l2, const DevTables* T, const uint32_t* d_tw, uint32_t* d_scratch,
                          uint8_t* d_flags, uint32_t ntasks) {
-  using G = Geo<LOGN>;
-  const size_t lds = 4 * (size_t)(G::LDS_WORDS + G::N) * sizeof(uint32_t);   // per wave: transposition slab + state word A
+  using G = Geo<LOGN, TM::LL>;
+  constexpr int TPB = TM::kTeamsPerBlock;
+  const size_t lds = TPB * (size_t)(G::LDS_WORDS + G::N) * sizeof(uint32_t);   // per team: transposition slab + state word A
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&row_kernel<LOGN, HAS_SHIFT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&row_kernel<LOGN, HAS_SHIFT, TM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  const unsigned grid = grid_for(ntasks, cfg.num_cus, 4, 8);   // <= num_cus * 8 blocks (scratch sizing)
-  hipLaunchKernelGGL((row_kernel<LOGN, HAS_SHIFT>), dim3(grid), dim3(256), lds, (hipStream_t)cfg.stream, d_prog, ops,
+  const unsigned grid = grid_for(ntasks, cfg.num_cus, TPB, 8);   // <= num_cus * 8 blocks (scratch sizing)
+  hipLaunchKernelGGL((row_kernel<LOGN, HAS_SHIFT, TM>), dim3(grid), dim3(TPB << TM::LL), lds, (hipStream_t)cfg.stream, d_prog, ops,
                      d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks);
   RZK_LAUNCH_CHECK();
   return 0;
@@ -2349,7 +2466,9 @@ int launch_rows(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t 
   switch (logn) {
     case 9: return has_shift ? launch_rows_t<9, true>(RZK_ROWS_ARGS) : launch_rows_t<9, false>(RZK_ROWS_ARGS);
     case 10: return has_shift ? launch_rows_t<10, true>(RZK_ROWS_ARGS) : launch_rows_t<10, false>(RZK_ROWS_ARGS);
-    case 11: return has_shift ? launch_rows_t<11, true>(RZK_ROWS_ARGS) : launch_rows_t<11, false>(RZK_ROWS_ARGS);
+    case 11:   // rotation terms are not built for N = 2048 (rzk_api.cpp, shift_ok)
+      if (has_shift) return -1;
+      return cfg.pair_poly ? launch_rows_t<11, false, PairTeam>(RZK_ROWS_ARGS) : launch_rows_t<11, false>(RZK_ROWS_ARGS);
   }
 #undef RZK_ROWS_ARGS
   return -1;
@@ -2376,6 +2495,8 @@ int launch_units(int logn, const LaunchCfg& cfg, const Program* d_prog, const Wa
     RZK_UNIT_CASE(10)
     case 11:   // rotation terms are not built for N = 2048 (rzk_api.cpp, shift_ok)
       if (has_shift) return -1;
+      if (cfg.pair_poly)
+        return has_vec ? launch_units_t<11, true, false, PairTeam>(RZK_UNIT_ARGS) : launch_units_t<11, false, false, PairTeam>(RZK_UNIT_ARGS);
       return has_vec ? launch_units_t<11, true, false>(RZK_UNIT_ARGS) : launch_units_t<11, false, false>(RZK_UNIT_ARGS);
   }
 #undef RZK_UNIT_ARGS
@@ -2388,10 +2509,18 @@ static int launch_shift_t(const LaunchCfg& cfg, const Program* d_prog, const Ope
                           uint8_t* d_flags, uint32_t ntasks) {
   using S = ShiftGeo<LOGN>;
   constexpr int WPB = ShiftCfg<LOGN>::WPB;
-  const size_t lds = (size_t)WPB * S::WORDS * sizeof(uint32_t);
+  // One wave's image is 8 N bytes.  The workgroup asks for at least 40 KiB so that a CU holds four workgroups = 4 waves per
+  // SIMD: with the 79 VGPRs the kernel needs, five or six would fit, and measured slower (response rows at N = 1024:
+  // 86.7 us against 77.5 us at four — the kernel is co-bound by the LDS pipe, more waves only add contention).
+  size_t lds = (size_t)WPB * S::WORDS * sizeof(uint32_t);
+  if (LOGN >= 10 && lds < 40 * 1024) lds = 40 * 1024;   // (N = 512 keeps its 6 waves per SIMD: 4-KiB images, measured fine in round 2)
   const unsigned grid = grid_for(ntasks, cfg.num_cus, WPB, 16);
-  hipLaunchKernelGGL((shift_row_kernel<LOGN>), dim3(grid), dim3(64 * WPB), lds, (hipStream_t)cfg.stream, d_prog, ops,
-                     T, d_flags, ntasks);
+  if (ops.trusted)
+    hipLaunchKernelGGL((shift_row_kernel<LOGN, true>), dim3(grid), dim3(64 * WPB), lds, (hipStream_t)cfg.stream, d_prog, ops,
+                       T, d_flags, ntasks);
+  else
+    hipLaunchKernelGGL((shift_row_kernel<LOGN, false>), dim3(grid), dim3(64 * WPB), lds, (hipStream_t)cfg.stream, d_prog, ops,
+                       T, d_flags, ntasks);
   RZK_LAUNCH_CHECK();
   return 0;
 }
@@ -2443,23 +2572,23 @@ size_t block_scratch_words(int logn, int num_cus) {
   return (size_t)num_cus * 2 * (size_t)(2 * kBlockMaxRows) * ((size_t)1 << logn);
 }
 
-template <int LOGN>
+template <int LOGN, class TM = WaveTeam>
 static int launch_blocks_t(const LaunchCfg& cfg, const Program* d_prog, const BlockPlan* d_plan, const Operands& ops,
                            const uint32_t* d_key_ntt, const double* d_key_l2, const DevTables* T, const uint32_t* d_tw,
                            uint32_t* d_scratch, uint8_t* d_flags, uint32_t ntasks) {
-  using G = Geo<LOGN>;
+  using G = Geo<LOGN, TM::LL>;
   const size_t lds = ((size_t)kBlockMaxSlots * G::N + (size_t)kBlockWaves * G::LDS_WORDS) * sizeof(uint32_t) +
                      kBlockMaxSlots * sizeof(double);
   // > 64 KiB of dynamic LDS needs an explicit opt-in.  The attribute is kept per device and contexts may live on
   // several devices / host threads, so it is set (idempotently, a host-side call of ~1 us) before every launch
   // rather than behind a process-wide "done" flag.
   {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&row_block_kernel<LOGN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&row_block_kernel<LOGN, TM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   uint32_t grid = ntasks < (uint32_t)cfg.num_cus * 2 ? ntasks : (uint32_t)cfg.num_cus * 2;   // scratch: num_cus * 2 lines
-  hipLaunchKernelGGL((row_block_kernel<LOGN>), dim3(grid), dim3(64 * kBlockWaves), lds, (hipStream_t)cfg.stream, d_prog,
+  hipLaunchKernelGGL((row_block_kernel<LOGN, TM>), dim3(grid), dim3(kBlockWaves << TM::LL), lds, (hipStream_t)cfg.stream, d_prog,
                      d_plan, ops, d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks);
   RZK_LAUNCH_CHECK();
   return 0;
@@ -2473,7 +2602,10 @@ int launch_row_blocks(int logn, const LaunchCfg& cfg, const Program* d_prog, con
   const uint32_t ntasks = (uint32_t)(batch * nblocks);
   switch (logn) {
     case 10: return launch_blocks_t<10>(cfg, d_prog, d_plan, ops, d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks);
-    case 11: return launch_blocks_t<11>(cfg, d_prog, d_plan, ops, d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks);
+    case 11:
+      if (cfg.pair_poly)   // eight two-wavefront teams: 16 coefficients per thread, 4 waves per SIMD beside 138 KiB of LDS
+        return launch_blocks_t<11, BlockPairTeam>(cfg, d_prog, d_plan, ops, d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks);
+      return launch_blocks_t<11>(cfg, d_prog, d_plan, ops, d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks);
   }
   return -1;
 }

@@ -25,52 +25,59 @@ const Tables& tables() {
   return t;
 }
 
-template <int LOGN>
+// A team of 2^LL threads (LL = 6: one wavefront, LL = 7: two wavefronts sharing the slab) replayed thread by thread;
+// every phase boundary is a team-wide barrier in the kernels, here simply the end of a loop over the threads.
+template <int LOGN, int LL = 6>
 struct Wave {
-  using G = Geo<LOGN>;
-  uint32_t x[64][G::E];
+  using G = Geo<LOGN, LL>;
+  static constexpr int T = G::LANES;
+  uint32_t x[T][G::E];
   uint32_t lds[G::LDS_WORDS];
 
   void forward(const uint32_t* tw, const PrimeConsts& pc) {   // x in phase-1 layout -> phase-3 layout
-    for (int l = 0; l < 64; ++l) { fwd_phase1<LOGN>(x[l], tw, pc); lds_put_p1<LOGN>(x[l], l, lds); }
-    for (int l = 0; l < 64; ++l) { lds_get_p2<LOGN>(x[l], l, lds); fwd_phase2<LOGN>(x[l], l, tw, pc); }
-    for (int l = 0; l < 64; ++l) lds_put_p2<LOGN>(x[l], l, lds);
-    for (int l = 0; l < 64; ++l) { lds_get_p3<LOGN>(x[l], l, lds); fwd_phase3<LOGN>(x[l], l, tw, pc); }
+    for (int l = 0; l < T; ++l) { fwd_phase1<LOGN, LL>(x[l], tw, pc); lds_put_p1<LOGN, LL>(x[l], l, lds); }
+    for (int l = 0; l < T; ++l) { lds_get_p2<LOGN, LL>(x[l], l, lds); fwd_phase2<LOGN, LL>(x[l], l, tw, pc); }
+    for (int l = 0; l < T; ++l) lds_put_p2<LOGN, LL>(x[l], l, lds);
+    for (int l = 0; l < T; ++l) { lds_get_p3<LOGN, LL>(x[l], l, lds); fwd_phase3<LOGN, LL>(x[l], l, tw, pc); }
   }
   void inverse(const uint32_t* tw, const PrimeConsts& pc) {   // phase-3 layout -> phase-1 layout
-    for (int l = 0; l < 64; ++l) { inv_phase3<LOGN>(x[l], l, tw, pc); lds_put_p3<LOGN>(x[l], l, lds); }
-    for (int l = 0; l < 64; ++l) { lds_get_p2<LOGN>(x[l], l, lds); inv_phase2<LOGN>(x[l], l, tw, pc); }
-    for (int l = 0; l < 64; ++l) lds_put_p2<LOGN>(x[l], l, lds);
-    for (int l = 0; l < 64; ++l) { lds_get_p1<LOGN>(x[l], l, lds); inv_phase1<LOGN>(x[l], tw, pc); }
+    for (int l = 0; l < T; ++l) { inv_phase3<LOGN, LL>(x[l], l, tw, pc); lds_put_p3<LOGN, LL>(x[l], l, lds); }
+    for (int l = 0; l < T; ++l) { lds_get_p2<LOGN, LL>(x[l], l, lds); inv_phase2<LOGN, LL>(x[l], l, tw, pc); }
+    for (int l = 0; l < T; ++l) lds_put_p2<LOGN, LL>(x[l], l, lds);
+    for (int l = 0; l < T; ++l) { lds_get_p1<LOGN, LL>(x[l], l, lds); inv_phase1<LOGN, LL>(x[l], tw, pc); }
   }
 };
 
-template <int LOGN>
+template <int LOGN, int LL = 6>
 int ntt_fwd(int pi, const uint32_t* in, uint32_t* out_std, uint32_t* out_mem) {
-  using G = Geo<LOGN>;
+  using G = Geo<LOGN, LL>;
   PrimeConsts pc = host::make_prime_consts(pi, G::N);
-  static Wave<LOGN> w;
-  for (int l = 0; l < 64; ++l)
+  static Wave<LOGN, LL> w;
+  for (int l = 0; l < G::LANES; ++l)
     for (int e = 0; e < G::E; ++e) w.x[l][e] = in[G::j_p1(l, e)];
   w.forward(tables().fwd[pi].data(), pc);
-  for (int l = 0; l < 64; ++l)
+  for (int l = 0; l < G::LANES; ++l)
     for (int c = 0; c < G::E; ++c) {
       uint32_t v = csub(csub(w.x[l][c], pc.twop), pc.p);
       out_std[G::j_p3(l, c)] = v;
       out_mem[G::mem_p3(l, c)] = v;
     }
+  // the 16-byte group index must address the same words
+  for (int l = 0; l < G::LANES; ++l)
+    for (int g = 0; g < G::E / 4; ++g)
+      if (G::key4(l, g) * 4 != G::mem_p3(l, 4 * g) || G::mem_p3(l, 4 * g + 3) != G::mem_p3(l, 4 * g) + 3) return -3;
   return 0;
 }
 
-template <int LOGN>
+template <int LOGN, int LL = 6>
 int ntt_inv(int pi, const uint32_t* in_std, uint32_t* out) {
-  using G = Geo<LOGN>;
+  using G = Geo<LOGN, LL>;
   PrimeConsts pc = host::make_prime_consts(pi, G::N);
-  static Wave<LOGN> w;
-  for (int l = 0; l < 64; ++l)
+  static Wave<LOGN, LL> w;
+  for (int l = 0; l < G::LANES; ++l)
     for (int c = 0; c < G::E; ++c) w.x[l][c] = in_std[G::j_p3(l, c)];
   w.inverse(tables().inv[pi].data(), pc);
-  for (int l = 0; l < 64; ++l)
+  for (int l = 0; l < G::LANES; ++l)
     for (int e = 0; e < G::E; ++e)
       out[G::j_p1(l, e)] = csub(mont_lazy(w.x[l][e], pc.ninv_r, pc.p, pc.npinv), pc.p);
   return 0;
@@ -164,6 +171,7 @@ int emul_shift_product(int logn, int pair, int passes, uint64_t q, const int64_t
   return -1;
 }
 int emul_ntt_fwd(int logn, int pi, const uint32_t* in, uint32_t* out_std, uint32_t* out_mem) {
+  if (logn == 1011) return ntt_fwd<11, 7>(pi, in, out_std, out_mem);   // N = 2048, two-wavefront team
   switch (logn) {
     case 9: return ntt_fwd<9>(pi, in, out_std, out_mem);
     case 10: return ntt_fwd<10>(pi, in, out_std, out_mem);
@@ -172,6 +180,7 @@ int emul_ntt_fwd(int logn, int pi, const uint32_t* in, uint32_t* out_std, uint32
   return -1;
 }
 int emul_ntt_inv(int logn, int pi, const uint32_t* in_std, uint32_t* out) {
+  if (logn == 1011) return ntt_inv<11, 7>(pi, in_std, out);
   switch (logn) {
     case 9: return ntt_inv<9>(pi, in_std, out);
     case 10: return ntt_inv<10>(pi, in_std, out);

@@ -68,6 +68,29 @@ def test_wave_ntt_matches_oracle_ntt(emul, logn, pi):
     assert np.array_equal(O.ntt_inverse(ref, p, psi), a)
 
 
+@pytest.mark.parametrize("pi", [0, 1, 2])
+def test_two_wavefront_team_ntt_matches_oracle_and_one_wave_layout(emul, pi):
+    """N = 2048 with a team of two wavefronts (Geo<11, 7>: 16 coefficients per thread, code 1011 in the emulator):
+    same transform, and the SAME words of the global NTT layout as the one-wavefront geometry — the resident key is
+    stored once and read by both."""
+    logn, N = 11, 2048
+    p = emul.emul_prime(pi)
+    psi = emul.emul_psi(pi, N)
+    rng = np.random.default_rng(1011 + pi)
+    a = rng.integers(0, p, N, dtype=np.uint32)
+    a[:4] = [0, 1, p - 1, p - 2]
+    std1, mem1 = np.empty(N, dtype=np.uint32), np.empty(N, dtype=np.uint32)
+    std2, mem2 = np.empty(N, dtype=np.uint32), np.empty(N, dtype=np.uint32)
+    assert emul.emul_ntt_fwd(logn, pi, _u32p(a), _u32p(std1), _u32p(mem1)) == 0
+    assert emul.emul_ntt_fwd(1011, pi, _u32p(a), _u32p(std2), _u32p(mem2)) == 0
+    ref = O.ntt_forward(a, p, psi)
+    assert np.array_equal(std2, ref) and np.array_equal(std1, ref)
+    assert np.array_equal(mem1, mem2)
+    back = np.empty(N, dtype=np.uint32)
+    assert emul.emul_ntt_inv(1011, pi, _u32p(std2), _u32p(back)) == 0
+    assert np.array_equal(back, a)
+
+
 def _polymul(emul, logn, np_, a, b):
     out = np.empty(1 << logn, dtype=np.int64)
     a = np.ascontiguousarray(a, dtype=np.int64)

@@ -218,6 +218,11 @@ def test_config5_shape_vs_oracle(torch_mod):
     dict(N=1024, shape=(1, 3, 1), V=3, env={"RZK_VEC_ROWS": 0}),
     dict(N=512, shape=(2, 5, 2), V=2, env={"RZK_VEC_ROWS": 0, "RZK_SLOT_SHARE_MIN": 0}),
     dict(N=2048, shape=(1, 3, 1), V=2, env={"RZK_VEC_ROWS": 0}),
+    # N = 2048 with one wavefront per polynomial (default: two), plain rows and through unit_kernel's HAS_VEC variant
+    dict(N=2048, shape=(1, 3, 1), V=2, env={"RZK_PAIR_POLY": 0}),
+    dict(N=2048, shape=(2, 5, 2), V=2, env={"RZK_PAIR_POLY": 0, "RZK_VEC_ROWS": 0, "RZK_BLOCK_MIN_LOGN": 12}),
+    # ... and two per polynomial without row blocks: grouped rows fall to the unit kernel's pairs
+    dict(N=2048, shape=(2, 5, 2), V=3, env={"RZK_BLOCK_MIN_LOGN": 12}),
 ])
 def test_forced_kernel_paths_vs_oracle(torch_mod, cfg):
     N, (n, k, l), V = cfg["N"], cfg["shape"], cfg["V"]

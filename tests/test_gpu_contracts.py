@@ -49,7 +49,7 @@ def test_trusted_mode_same_bytes_default_still_checks(torch_mod, N):
         sc = ctx.sum_commit(gs, xs, rs, rp2, ys, yp2)
         sz = ctx.sum_response(ys, yp2, rs, rp2, d2)
         out += list(sc) + list(sz) + [ctx.sum_verify(sz[0], sz[1], sc[0], sc[1], gs, sc[2], sc[3], sc[4], d2)]
-        out += [ctx.polymul(g, g), ctx.matvec(2, ys[:, 0]), ctx.commit(x, r)[0]]
+        out += [ctx.polymul(g, g), ctx.matvec(2, np.ascontiguousarray(ys[:, 0])), ctx.commit(x, r)[0]]
         return out
 
     checked = everything()
@@ -95,9 +95,10 @@ def test_coefficient_of_exactly_two_to_31_is_rejected(torch_mod, N):
             want = [1] * B
             want[pos[0]] = 0
             assert acc.tolist() == want, (name, val)
-    g = gs[:, 0]
-    lc = ctx.linear_commit(g, xs[:, 0], rs[:, 0], rp, ys[:, 0], yp)
-    lz = ctx.linear_response(ys[:, 0], yp, rs[:, 0], rp, d)
+    C = np.ascontiguousarray
+    g, x0, r0, y0 = C(gs[:, 0]), C(xs[:, 0]), C(rs[:, 0]), C(ys[:, 0])
+    lc = ctx.linear_commit(g, x0, r0, rp, y0, yp)
+    lz = ctx.linear_response(y0, yp, r0, rp, d)
     assert ctx.linear_verify(lz[0], lz[1], lc[0], lc[1], g, lc[2], lc[3], lc[4], d).tolist() == [1] * B
     gb = g.copy()
     gb[1, 4] = 1 << 31
@@ -178,7 +179,7 @@ def test_prof_names_the_kernels(torch_mod):
     durs = ctx.prof_read_all()
     ctx.prof_enable(False)
     assert acc.cpu().tolist() == [1, 1]
-    assert [nm for nm, _ in names] == ["unit_kernel<10, false, false>", "shift_row_kernel<10>", "unit_kernel<10, false, true>"]
+    assert [nm for nm, _ in names] == ["unit_kernel<10, false, false>", "shift_row_kernel<10, false>", "unit_kernel<10, false, true>"]
     # Open at (1,3,1): commit reads x, r(3), y(3) and stores c(2), t(1); response reads d, y(3), r(3), stores z(3);
     # verify reads z(3), t, c1, d
     assert [nb for _, nb in names] == [10 * 8 * 1024 * 2, 10 * 8 * 1024 * 2, 6 * 8 * 1024 * 2]

@@ -25,6 +25,7 @@ KNOBS = [
     {"RZK_UPT": 64},   # all units of a proof in one wavefront (what batches >= 4096 take), here at batch <= 5
     {"RZK_SLOT_SHARE_MIN": 0, "RZK_ROW_GROUPS": 0},
     {"RZK_BLOCK_MIN_LOGN": 10},
+    {"RZK_PAIR_POLY": 0},   # N = 2048: one wavefront per polynomial (the round-2 kernels) instead of two
 ]
 
 

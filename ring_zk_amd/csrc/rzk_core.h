@@ -150,10 +150,10 @@ struct Geo {
   // phase-3 register c of `lane`; groups of 4 registers form one 16-byte coalesced access.  The layout is
   // defined by the ONE-wavefront geometry of the ring degree (what the resident key and the batched transforms
   // use); a two-wavefront team addresses the same words through its own (lane, c) -> position map.
-  static constexpr int E64 = N / 64;
+  static constexpr int LOGE64 = LOGN - 6;
   RZK_HD static int mem_p3(int lane, int c) {
-    const int j = lane * E + c, l64 = j / E64, c64 = j % E64;
-    return (c64 >> 2) * 256 + l64 * 4 + (c64 & 3);
+    const unsigned j = (unsigned)(lane * E + c), l64 = j >> LOGE64, c64 = j & ((1u << LOGE64) - 1u);
+    return (int)((c64 >> 2) * 256u + l64 * 4u + (c64 & 3u));
   }
   // index, in 16-byte units, of the group g (registers 4g .. 4g+3) of `lane` in that layout
   RZK_HD static int key4(int lane, int g) { return mem_p3(lane, 4 * g) >> 2; }
@@ -427,6 +427,18 @@ RZK_HD int64_t crt_center(uint32_t r0, uint32_t r1, uint32_t r2, int np, const P
 RZK_HD uint32_t crt_fold0(uint32_t r, int np, const PrimeConsts* pc, const CrtConsts& C) {
   return csub(csub(r + C.hmod[np][0], pc[0].twop), pc[0].p);
 }
+// ---- one- and two-prime results in SIGN-TEST form (no offset) -----------------------------------------------------
+// Rows that need at most two primes (key x ternary, key x Gaussian: the commitments, t, the verifier relation) skip
+// the offset: d0 = r0 mod p0 is one conditional subtract instead of add + two, the second digit needs no H terms, and
+// the sign of X comes from one 64-bit compare of X' = d0 + d1 p0 against (P+1)/2.  About a third fewer vector
+// instructions per coefficient than crt_fold0 / crt_digit1 / crt_finish_zq on this path (three-prime rows keep the
+// offset form: its third step would need the 64-bit low part again).  Requires p0 < q.
+RZK_HD uint32_t crt1_zq(uint32_t r0, const PrimeConsts* pc, const CrtConsts& C) {   // np = 1: X mod q in [0,q)
+  const uint32_t d0 = csub(r0, pc[0].p);
+  return d0 >= C.half1 ? d0 + (C.q - pc[0].p) : d0;   // X = d0 - p0 < 0  ->  X + q
+}
+RZK_HD uint32_t crt2_digit0(uint32_t r0, const PrimeConsts* pc) { return csub(r0, pc[0].p); }
+RZK_HD uint32_t crt2_zq(uint32_t r1, uint32_t d0, const PrimeConsts* pc, const CrtConsts& C);   // (defined below addq / montq_u)
 // ---- 32-bit arithmetic mod q (q may exceed 2^31, so sums can wrap 32 bits; handled by comparing first)
 RZK_HD uint32_t addq(uint32_t a, uint32_t b, uint32_t q) {   // a, b in [0,q)
   const uint32_t nb = q - b;
@@ -452,6 +464,13 @@ RZK_HD uint32_t zq_from_centered(int32_t a, uint32_t q) { return (uint32_t)a + (
 RZK_HD int64_t center_from_zq(uint32_t u, const CrtConsts& C) {
   const uint32_t lo = u > C.qhalf ? u - C.q : u;   // |.| <= (q-1)/2 < 2^31: the 32-bit pattern is the int32 value
   return (int64_t)(int32_t)lo;
+}
+RZK_HD uint32_t crt2_zq(uint32_t r1, uint32_t d0, const PrimeConsts* pc, const CrtConsts& C) {   // np = 2: X mod q in [0,q)
+  const uint32_t t1 = r1 + pc[1].twop - d0;                                  // r1 < 2 p1, d0 < p0 < 2 p1  ->  (0, 4 p1)
+  const uint32_t d1 = csub(mont_lazy(t1, C.inv01_r, pc[1].p, pc[1].npinv), pc[1].p);
+  const uint32_t va = addq(d0, montq_u(d1, C.c1, C), C.q);                   // (d0 + d1 p0) mod q
+  const uint64_t x01 = (uint64_t)d1 * pc[0].p + d0;                          // X mod p0 p1, exact
+  return subq(va, x01 >= C.half2 ? C.pmodq[2] : 0u, C.q);                    // negative X: minus P mod q
 }
 // second digit d1 = (X' mod p1 - d0) * p0^{-1} mod p1 from the prime-1 residue r and d0
 RZK_HD uint32_t crt_digit1(uint32_t r, uint32_t d0, int np, const PrimeConsts* pc, const CrtConsts& C) {

@@ -139,6 +139,7 @@ struct WaveTeam {
   __device__ __forceinline__ static void sync() { wave_sync(); }
   __device__ __forceinline__ static float sum_f32(float v) { return wave_sum_f32(v); }
   __device__ __forceinline__ static uint64_t sum_u56(uint64_t v) { return wave_sum_u56(v); }
+  __device__ __forceinline__ static uint32_t max_u32(uint32_t v) { return wave_max_u32(v); }
 };
 struct PairTeam {
   static constexpr int LL = 7;
@@ -152,6 +153,15 @@ struct PairTeam {
     const float tot = xf[0] + xf[1];
     __syncthreads();   // the words are free again
     return uniform_f32(tot);
+  }
+  __device__ __forceinline__ static uint32_t max_u32(uint32_t v) {
+    __shared__ uint32_t xm[2];
+    const uint32_t w = wave_max_u32(v);
+    if ((threadIdx.x & 63) == 0) xm[(threadIdx.x >> 6) & 1] = w;
+    __syncthreads();
+    const uint32_t tot = xm[0] > xm[1] ? xm[0] : xm[1];
+    __syncthreads();
+    return tot;
   }
   __device__ __forceinline__ static uint64_t sum_u56(uint64_t v) {
     __shared__ uint64_t xq[2];
@@ -199,6 +209,15 @@ struct BlockPairTeam {
     const float tot = xf[0] + xf[1];
     sync();   // the words are free again
     return uniform_f32(tot);
+  }
+  __device__ __forceinline__ static uint32_t max_u32(uint32_t v) {
+    uint32_t* xw = words() + 2;
+    const uint32_t w = wave_max_u32(v);
+    if ((threadIdx.x & 63) == 0) xw[(threadIdx.x >> 6) & 1] = w;
+    sync();
+    const uint32_t tot = xw[0] > xw[1] ? xw[0] : xw[1];
+    sync();
+    return tot;
   }
   __device__ __forceinline__ static uint64_t sum_u56(uint64_t v) {   // (rare path: two 28-bit halves through the two words)
     const uint64_t w = wave_sum_u56(v);
@@ -349,7 +368,22 @@ __device__ __forceinline__ const int64_t* operand_ptr(const Operands& ops, uint3
 // measure (the first prime pass): nrm2 = an upper bound of the polynomial's 2-norm (wave-uniform), and — check — the
 // fused norm predicate sum c^2 < limit, exact (norm_below); unless `trusted`, the same pass proves that every
 // coefficient is canonical (canon_lo_mx).  Later passes re-read the low words only.
-template <int LOGN, class TM = WaveTeam>
+// How the measure pass is laid out (MODE): the arithmetic is the same, the register footprint is not.
+//   LL_FUSED   every coefficient tested, squared and lifted as it arrives, all E loads in flight (unit_kernel)
+//   LL_HALVES  the same in two rolled halves: E/2 sixty-four-bit coefficients in flight
+//   LL_L1INF   all E loads in flight, low words into an int array first; sum v^2 bounded by |v|_1 |v|_inf
+enum : int { LL_FUSED = 0, LL_HALVES = 1, LL_L1INF = 2 };
+// row_kernel keeps its running sum (and, in a vector x vector term, the first operand's transform) in registers across
+// the load.  Measured on the Sum (4,9,4) / Linear configurations (A/B of prebuilt libraries, round 3): LL_L1INF for
+// both operands 224-225 k / 4.35 M proofs/s, LL_HALVES for both 221 k / 4.26 M, LL_FUSED spills (128 VGPRs + 156
+// bytes of scratch: 213 k / 4.10 M).  Teams of two (N = 2048) stay spill-free only with LL_HALVES.
+#ifndef RZK_ROW_MODE_B
+#define RZK_ROW_MODE_B (TM::LL == 7 ? LL_HALVES : LL_L1INF)   // row_kernel, a term's first operand
+#endif
+#ifndef RZK_ROW_MODE_A
+#define RZK_ROW_MODE_A (TM::LL == 7 ? LL_HALVES : LL_L1INF)   // ... second operand of a vector x vector term
+#endif
+template <int LOGN, class TM = WaveTeam, int MODE = LL_FUSED>
 __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict__ src, int lane, const PrimeConsts& pc,
                                           bool measure, float& nrm2, bool check, uint64_t limit, bool& below,
                                           uint32_t qhalf, bool trusted, bool& fault) {
@@ -358,7 +392,63 @@ __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict
     // one pass: the 64-bit coefficient is tested, squared into the float sum and lifted as soon as it arrives, so that
     // only the lifted residues stay in registers (no second copy of the polynomial)
     float part = 0.f;
-    if (trusted) {
+    if (MODE == LL_L1INF) {
+      int32_t v[G::E];
+      uint32_t bad = 0;
+#pragma unroll
+      for (int e = 0; e < G::E; ++e) v[e] = trusted ? (int32_t)src[G::j_p1(lane, e)] : canon_lo(src[G::j_p1(lane, e)], qhalf, bad);
+      uint64_t sum = 0;
+      uint32_t mxa = 0;
+#pragma unroll
+      for (int e = 0; e < G::E; e += 2) {
+        const uint32_t u0 = (uint32_t)v[e], u1 = (uint32_t)v[e + 1];
+        const uint32_t a0 = v[e] < 0 ? 0u - u0 : u0;
+        const uint32_t a1 = v[e + 1] < 0 ? 0u - u1 : u1;
+        sum += (uint64_t)a0 + a1;
+        mxa = a0 > mxa ? a0 : mxa;
+        mxa = a1 > mxa ? a1 : mxa;
+      }
+      const float l1 = (float)TM::sum_u56(sum) * (1.0f + 0x1p-20f);
+      const uint32_t wmx = TM::max_u32(mxa);
+      if (!trusted) fault = fault || __any(bad != 0) || wmx > qhalf;
+      // sum v^2 <= |v|_1 |v|_inf; handed on as if every thread of the team carried an equal share
+      part = l1 * (float)wmx * (1.0f + 0x1p-20f) * (1.0f / (float)G::LANES);
+      if (check) {   // the exact predicate needs the exact sum: float squares of the same registers
+        float sq = lane_sum_sq_f32<G::E>(v);
+        const float ssq = TM::sum_f32(sq);
+        const double sd = (double)ssq, lim = (double)limit;
+        if (sd * (1.0 + 2.0 * (double)kNormSlack) < lim) below = true;
+        else if (sd * (1.0 - 2.0 * (double)kNormSlack) >= lim) below = false;
+        else below = TM::sum_u56(lane_sum_sq_exact<G::E>(v)) < limit;
+      }
+#pragma unroll
+      for (int e = 0; e < G::E; ++e) x[e] = lift(v[e], pc);
+    } else if (MODE == LL_HALVES) {
+      // two rolled halves: E/2 sixty-four-bit coefficients in flight instead of E.  For the kernels that keep a running
+      // sum in registers across the load (row_kernel, the group and slot kernels) this is what fits 128 VGPRs without
+      // spilling (row_kernel<10>: 116 VGPRs against 128 + 156 bytes of scratch); unit_kernel, with nothing else live,
+      // is better off with all loads in flight at once (116 against 132 VGPRs).
+      uint32_t bad = 0, mx = 0;
+      constexpr int H = G::E / 2;
+#pragma unroll 1
+      for (int h = 0; h < 2; ++h) {
+        uint32_t y[H];
+#pragma unroll
+        for (int e2 = 0; e2 < H; ++e2) {
+          const int64_t c = src[(size_t)(h * H + e2) * G::LANES + lane];
+          const int32_t v = trusted ? (int32_t)c : canon_lo_mx(c, qhalf, bad, mx);
+          const float f = (float)v;
+          part = __builtin_fmaf(f, f, part);
+          y[e2] = lift(v, pc);
+        }
+#pragma unroll
+        for (int e2 = 0; e2 < H; ++e2) {
+          x[e2] = h == 0 ? y[e2] : x[e2];
+          x[H + e2] = h == 1 ? y[e2] : x[H + e2];
+        }
+      }
+      if (!trusted) fault = fault || canon_fail(bad, mx, qhalf);
+    } else if (trusted) {
 #pragma unroll
       for (int e = 0; e < G::E; ++e) {
         const int32_t v = (int32_t)src[G::j_p1(lane, e)];
@@ -379,7 +469,7 @@ __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict
     }
     const float ss = TM::sum_f32(part);
     nrm2 = norm2_upper(ss);
-    if (check) {
+    if (check && MODE != LL_L1INF) {
       const double sd = (double)ss, lim = (double)limit;
       if (sd * (1.0 + 2.0 * (double)kNormSlack) < lim) {
         below = true;
@@ -607,7 +697,7 @@ __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const 
   bool below = true, fault = false;
   const bool chk = first && (tm.kind & (TERM_CHECK | TERM_CHECK2));
   const bool trusted = ops.trusted != 0;
-  load_lift<LOGN, TM>(x, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), ln, pc, first, nb, chk, ops.norm_limit, below, qhalf, trusted, fault);
+  load_lift<LOGN, TM, RZK_ROW_MODE_B>(x, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), ln, pc, first, nb, chk, ops.norm_limit, below, qhalf, trusted, fault);
   if (chk && !below && (lane & 63) == 0) fail_check(flags + bo, ops.pad != 0, (tm.kind & TERM_CHECK2) != 0);
   wave_fwd<LOGN, TM>(x, ln, lds, twf, pc);
   if (HAS_VEC && (tm.kind & TERM_KIND_MASK) == TERM_VEC) {
@@ -617,7 +707,7 @@ __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const 
     for (int c = 0; c < E; ++c) xb[c] = csub(mont_lazy(x[c], pc.ninv_r2, pc.p, pc.npinv), pc.p);
     float na = 0.f;
     bool unused_below = true;
-    load_lift<LOGN, TM>(x, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), ln, pc, first, na, false, 0, unused_below, qhalf, trusted, fault);
+    load_lift<LOGN, TM, RZK_ROW_MODE_A>(x, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), ln, pc, first, na, false, 0, unused_below, qhalf, trusted, fault);
     wave_fwd<LOGN, TM>(x, ln, lds, twf, pc);
     if (first) bound = bound_fma(na, nb, bound);   // |a (*) b|_inf <= |a|_2 |b|_2
     if (tm.sign >= 0) {
@@ -959,16 +1049,31 @@ __device__ __forceinline__ bool inverse_fold_global(int pi, int np, uint32_t* ac
     for (int g = 0; g < E / 4; ++g) sb[g] = B4[G::own4(li, g)];
   }
   if (pi == 0) {
-#pragma unroll
-    for (int e = 0; e < E; ++e) acc[e] = crt_fold0(acc[e], np, T.pc, T.crt);
     if (np == 1) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) acc[e] = crt_finish_zq(acc[e], 1, T.crt);
+      for (int e = 0; e < E; ++e) acc[e] = crt1_zq(acc[e], T.pc, T.crt);
       return true;
+    }
+    if (np == 2) {   // sign-test form (rzk_core.h): the first digit is the canonical residue itself
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[e] = crt2_digit0(acc[e], T.pc);
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) acc[e] = crt_fold0(acc[e], np, T.pc, T.crt);
     }
 #pragma unroll
     for (int g = 0; g < E / 4; ++g) A4[G::own4(li, g)] = make_uint4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
     return false;
+  }
+  if (pi == 1 && np == 2) {
+#pragma unroll
+    for (int g = 0; g < E / 4; ++g) {
+      const uint4 dv = sa[g];
+      const uint32_t d0[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[4 * g + i] = crt2_zq(acc[4 * g + i], d0[i], T.pc, T.crt);
+    }
+    return true;
   }
   if (pi == 1) {
 #pragma unroll
@@ -980,17 +1085,12 @@ __device__ __forceinline__ bool inverse_fold_global(int pi, int np, uint32_t* ac
       for (int i = 0; i < 4; ++i) {
         const uint32_t d1 = crt_digit1(acc[4 * g + i], d0[i], np, T.pc, T.crt);
         va[i] = crt_value01_modq(d0[i], d1, T.crt);
-        vb[i] = np == 3 ? crt_value01_modp2(d0[i], d1, T.pc, T.crt) : 0u;
+        vb[i] = crt_value01_modp2(d0[i], d1, T.pc, T.crt);
       }
-      if (np == 3) {
-        A4[G::own4(li, g)] = make_uint4(va[0], va[1], va[2], va[3]);
-        B4[G::own4(li, g)] = make_uint4(vb[0], vb[1], vb[2], vb[3]);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[4 * g + i] = crt_finish_zq(va[i], 2, T.crt);
-      }
+      A4[G::own4(li, g)] = make_uint4(va[0], va[1], va[2], va[3]);
+      B4[G::own4(li, g)] = make_uint4(vb[0], vb[1], vb[2], vb[3]);
     }
-    return np == 2;
+    return false;
   }
 #pragma unroll
   for (int g = 0; g < E / 4; ++g) {

@@ -119,6 +119,9 @@ int polymul(int np, uint64_t q, const int64_t* a, const int64_t* b, int64_t* out
       if (np >= 3) crt_fold2(res[2][l][e], pc, C, stA, stB);
       const int64_t v2 = crt_finish(stA, np, C);
       if (v1 != v2) return -2;
+      // ... and the sign-test forms of the one- and two-prime rows (unit_kernel)
+      if (np == 1 && center_from_zq(crt1_zq(res[0][l][e], pc, C), C) != v1) return -4;
+      if (np == 2 && center_from_zq(crt2_zq(res[1][l][e], crt2_digit0(res[0][l][e], pc), pc, C), C) != v1) return -5;
       out[G::j_p1(l, e)] = v2;
     }
   return 0;

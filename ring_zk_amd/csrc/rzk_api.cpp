@@ -101,6 +101,7 @@ struct rzk_ctx {
   bool use_groups = true;
   uint32_t units_per_task = 0;         // 0 = automatic (RZK_UPT overrides, tuning)
   bool vec_rows = true;                // programs with vector x vector products: row_kernel (RZK_VEC_ROWS=0: unit_kernel)
+  bool unit_io = false;                // key-product programs through unit_io_kernel (every operand read once; RZK_UNIT_IO=1): measured slower, see DESIGN.md
   bool pair_poly = true;               // N = 2048: two wavefronts per polynomial (RZK_PAIR_POLY=0: one, the round-2 kernels)
   bool trusted = false;                // rzk_ctx_trust_device_outputs: skip the canonical test of loaded coefficients
   bool use_pairs = true;               // unit_kernel: pair rows that share their last operand (RZK_PAIRS=0 turns it off, tuning)
@@ -170,7 +171,7 @@ uint64_t isqrt_u64(uint64_t x) {
 
 LaunchCfg cfg_of(rzk_ctx* c) {
   (void)hipSetDevice(c->device);   // the calling thread may have another current device
-  return LaunchCfg{(void*)c->stream, c->num_cus, c->pair_poly ? 1 : 0};
+  return LaunchCfg{(void*)c->stream, c->num_cus, c->pair_poly ? 1 : 0, c->unit_io ? 1 : 0};
 }
 
 int arena_reserve(rzk_ctx* c, Arena& a, size_t bytes) {
@@ -829,6 +830,8 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
     else if (dp.d_slots) pi.kernel = "fwd_slots_kernel<" + L + "> + row_slots_kernel<" + L + ">";
     else if (dp.has_vec && c->vec_rows)
       pi.kernel = "row_kernel<" + L + ", " + (dp.has_shift ? "true" : "false") + (pairs ? ", PairTeam>" : ">");
+    else if (!dp.has_vec && c->unit_io)
+      pi.kernel = "unit_io_kernel<" + L + ", " + (dp.has_shift ? "true" : "false") + (pairs ? ", PairTeam>" : ">");
     else
       pi.kernel = "unit_kernel<" + L + ", " + (dp.has_vec ? "true" : "false") + ", " + (dp.has_shift ? "true" : "false") +
                   (pairs ? ", PairTeam>" : ">");
@@ -1066,6 +1069,7 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
   if (const char* e = std::getenv("RZK_UPT")) c->units_per_task = (uint32_t)std::atoi(e);
   if (const char* e = std::getenv("RZK_VEC_ROWS")) c->vec_rows = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_PAIR_POLY")) c->pair_poly = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RZK_UNIT_IO")) c->unit_io = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_BLOCK_MIN_LOGN")) c->block_min_logn = (uint32_t)std::atoi(e);   // 12 = never
 
   // twiddle tables: 3 primes x {fwd, inv} x kTableLen

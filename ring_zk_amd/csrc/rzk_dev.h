@@ -184,6 +184,7 @@ struct LaunchCfg {
   void* stream;   // hipStream_t
   int num_cus;
   int pair_poly;  // N = 2048: two wavefronts per polynomial (PairTeam) in unit_kernel / row_kernel / row_block_kernel
+  int unit_io;    // key-product programs through unit_io_kernel (operands read once) instead of unit_kernel
 };
 
 // units_per_task: how many consecutive units of one batch entry a wavefront evaluates back to back (all of them =

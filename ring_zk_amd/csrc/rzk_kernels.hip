@@ -343,7 +343,10 @@ __device__ __forceinline__ void input_fault(const Operands& ops, uint8_t* flags,
 
 __device__ __forceinline__ const int64_t* operand_ptr(const Operands& ops, uint32_t op, uint32_t off,
                                                        uint32_t b, uint32_t bo, int n_coef) {
-  const uint32_t idx = ops.outer[op] ? bo : b;
+  uint32_t idx = ops.outer[op] ? bo : b;
+#ifdef RZK_EXPERIMENT_ALIAS   // diagnostic builds only: every batch entry uses the data of entry (index mod 64), so
+  idx &= (uint32_t)(RZK_EXPERIMENT_ALIAS - 1);   // (a power of two: 64 keeps operands and results in L2, 1024 in the Infinity Cache) — what the launch would cost without its HBM traffic
+#endif
   return ops.base[op] + ((uint64_t)idx * ops.stride[op] + off) * (uint64_t)n_coef;
 }
 
@@ -1396,6 +1399,272 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
     const uint64_t cyc1 = __builtin_amdgcn_s_memtime();
     o[8] = (uint32_t)(cyc1 - cyc0);   // shader-clock cycles of the wave's lifetime
     o[9] = (uint32_t)t_load, o[10] = (uint32_t)t_fwd, o[11] = (uint32_t)t_mac, o[12] = (uint32_t)t_inv, o[13] = (uint32_t)t_fin, o[14] = (uint32_t)t_rot;
+  }
+#endif
+}
+
+// =============================================================================================
+// unit_io_kernel ("item outer"): the default evaluation of KEY-PRODUCT programs — every operand is read from HBM ONCE.
+//
+// Why: the round-3 experiment of DESIGN.md §6 (the same launches with every operand L2-resident: commit 130 -> 100 us,
+// verify 76 -> 65 us) showed that unit_kernel's launches are co-bound by HBM traffic: 1.8 x the algorithmic bytes, because
+// its prime-outer loop re-reads every operand for the second prime and keeps the Garner state of a row in global lines
+// across a whole prime pass (evicted long before it is read back).  Here the loops are swapped:
+//   for every item (operand): load it once — canonical test, norm measurement, norm mark — keep the low words in
+//     registers, and for primes 0 and 1: lift, forward transform, multiply into that prime's sum of every row it feeds;
+//   the sums wait in parking spots between items: row A / prime 0 in LDS (buffer P), the others (row A / prime 1, a
+//     pair's row B) in the team's scratch lines in global memory, which are re-used within microseconds and stay in L2;
+//   then per row: inverse transform of prime 0, first digit in REGISTERS, inverse transform of prime 1, sign-test
+//     reconstruction (crt2_zq), finish_row.  No Garner state ever leaves the registers.
+// Two primes are computed for every row (a row that one prime would cover is still exact with two).  Rows that need
+// the third prime (full-range operands: Mat::dot on arbitrary vectors, tests) are detected once all operands have been
+// measured and take one more pass over the items for prime 2 (operands re-read: the rare path), with the offset-form
+// Garner steps in registers.  Everything else — units, pairs, rotation terms first, finish_row, norm marks, input
+// faults, progress priorities, teams of one or two wavefronts — is unit_kernel's.
+// Parking lines of a team (N words each): 0 = A/p1, 1 = B/p0, 2 = B/p1, 3 = A/p2, 4 = rotation sums, 5 = B/p2.
+// =============================================================================================
+template <int LOGN, class TM = WaveTeam>
+__device__ __forceinline__ void load_measure(int32_t* v, const int64_t* __restrict__ src, int lane, bool measure, float& nrm2,
+                                             bool check, uint64_t limit, bool& below, uint32_t qhalf, bool trusted, bool& fault) {
+  using G = Geo<LOGN, TM::LL>;
+  if (!measure || trusted) {
+#pragma unroll
+    for (int e = 0; e < G::E; ++e) v[e] = (int32_t)src[G::j_p1(lane, e)];
+  } else {
+    uint32_t bad = 0, mx = 0;
+#pragma unroll
+    for (int e = 0; e < G::E; ++e) v[e] = canon_lo_mx(src[G::j_p1(lane, e)], qhalf, bad, mx);
+    fault = fault || canon_fail(bad, mx, qhalf);
+  }
+  if (measure) {
+    const float ss = TM::sum_f32(lane_sum_sq_f32<G::E>(v));
+    nrm2 = norm2_upper(ss);
+    if (check) below = norm_below<G::E, TM>(v, ss, limit);
+  }
+}
+// a parked sum (16-byte slots of the team's own threads) -> registers
+template <int LOGN, class TM, class P4T>
+__device__ __forceinline__ void unpark(uint32_t* a, P4T P4, int lane) {
+  using G = Geo<LOGN, TM::LL>;
+#pragma unroll
+  for (int g = 0; g < G::E / 4; ++g) {
+    const uint4 v = P4[G::own4(lane, g)];
+    a[4 * g] = v.x, a[4 * g + 1] = v.y, a[4 * g + 2] = v.z, a[4 * g + 3] = v.w;
+  }
+}
+
+template <int LOGN, bool HAS_SHIFT, class TM = WaveTeam>
+__global__ void __launch_bounds__(TM::kTeamsPerBlock << TM::LL, (TM::LL == 7 || LOGN == 10 ? 4 : 1))   // 16 coefficients per thread: 4 waves per SIMD
+unit_io_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp, const Operands ops,
+               const uint32_t* __restrict__ key_ntt, const double* __restrict__ key_l2, const DevTables* __restrict__ Tp,
+               const uint32_t* __restrict__ tw_all, uint32_t* __restrict__ scratch, uint8_t* __restrict__ flags,
+               const uint32_t ntasks, const uint32_t units_per_task, const uint32_t tasks_per_entry,
+               const uint32_t work_per_task) {
+  using G = Geo<LOGN, TM::LL>;
+  constexpr int E = G::E;
+  constexpr int N = G::N;
+  constexpr bool OPQ = true;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const int lane = threadIdx.x & (G::LANES - 1);
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> TM::LL);
+  constexpr int TPB = TM::kTeamsPerBlock;
+  uint32_t* lds = smem + wave * (G::LDS_WORDS + N);             // transposition slab, then P
+  uint4* P4 = reinterpret_cast<uint4*>(lds + G::LDS_WORDS);
+  uint32_t* st = scratch + ((size_t)blockIdx.x * TPB + wave) * (size_t)(kScratchLines * N + 16);
+  uint32_t* st_sh = st + 4 * N;
+#if RZK_STAMPS
+  const uint64_t stamp0 = __builtin_amdgcn_s_memrealtime();
+  const uint64_t cyc0 = __builtin_amdgcn_s_memtime();
+#endif
+  const DevTables& T = *Tp;
+  const uint32_t qhalf = T.crt.qhalf;
+  const bool trusted = ops.trusted != 0;
+  const uint32_t nunits = wp->nunits;
+  const uint32_t first_task = blockIdx.x * TPB + wave;
+  const uint32_t my_tasks = first_task < ntasks ? (ntasks - first_task + gridDim.x * TPB - 1) / (gridDim.x * TPB) : 0;
+  const uint32_t work_total = my_tasks * work_per_task;
+  uint32_t work_done = 0;
+#define RZK_STEP_PRIORITY()                             \
+  do {                                                  \
+    set_progress_priority(work_done, work_total);       \
+    ++work_done;                                        \
+  } while (0)
+
+  for (uint32_t task = first_task; task < ntasks; task += gridDim.x * TPB) {
+    const uint32_t b = task / tasks_per_entry;
+    const uint32_t u0 = (task - b * tasks_per_entry) * units_per_task;
+    const uint32_t u1 = u0 + units_per_task < nunits ? u0 + units_per_task : nunits;
+    const uint32_t bo = ops.group > 1 ? b / ops.group : b;
+#pragma unroll 1
+    for (uint32_t ui = u0; ui < u1; ++ui) {
+      const Unit un = table_load(&wp->units[ui]);
+      const Row rowA = table_load(&prog->rows[un.rowA]);
+      const bool pair = un.rowB != kNoRow;
+      const uint32_t nit = un.nitems;
+      const bool has_shift = HAS_SHIFT && rowA.nshift > 0;
+      if (has_shift) {
+        // challenge products first (rotations, image in slab + P); their sum mod q waits in the team's line 4
+        bool fault = false;
+#pragma unroll 1
+        for (uint32_t t = 0; t < rowA.nshift; ++t) {
+          const Term tm = table_load(&prog->terms[rowA.term0 + rowA.nterms + t]);
+          const int64_t* __restrict__ pa = operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N);
+          int32_t a[E];
+          if (trusted) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) a[e] = (int32_t)pa[G::j_p1(lane, e)];
+          } else {
+            uint32_t abad = 0, amx = 0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) a[e] = canon_lo_mx(pa[G::j_p1(lane, e)], qhalf, abad, amx);
+            fault = fault || canon_fail(abad, amx, qhalf);
+          }
+          shift_product<LOGN, false, true>(st_sh, t == 0, tm.sign < 0, a, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane,
+                                           reinterpret_cast<int32_t*>(lds), T, fault, trusted);
+        }
+        if (fault) input_fault(ops, flags, bo, lane);
+        wave_sync();   // the image is dead: slab and P may be overwritten
+      }
+      if (nit == 0) {   // no products: additions / rotation terms only
+        uint32_t u[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) u[e] = 0;
+        RZK_STEP_PRIORITY();
+        finish_row<LOGN, 16, TM>(u, prog, rowA, ops, b, bo, lane, T, flags, has_shift ? st_sh : nullptr);
+        continue;
+      }
+      // ---- the items: pass 0 = primes 0 and 1 (operands measured), pass 1 = prime 2, only when the bound asks for it
+      float boundA = 0.f, boundB = 0.f;
+      bool fault = false, haveA = false;
+      int np = 2;
+#pragma unroll 1
+      for (int pass = 0; pass < (np == 3 ? 2 : 1); ++pass) {
+        haveA = false;
+#pragma unroll 1
+        for (uint32_t it = 0; it < nit; ++it) {
+          const bool last = it + 1 == nit;
+          int ln = lane;
+          RZK_OPAQUE(ln);
+          const Item im = table_load(&wp->items[un.item0 + it]);
+          int32_t v[E];
+          float nb = 0.f;
+          bool below = true;
+          const bool chk = pass == 0 && (im.flags & (TERM_CHECK | TERM_CHECK2));
+          load_measure<LOGN, TM>(v, operand_ptr(ops, im.b_op, im.b_off, b, bo, N), ln, pass == 0, nb, chk, ops.norm_limit, below,
+                                 qhalf, trusted, fault);
+          if (chk && !below && (lane & 63) == 0) fail_check(flags + bo, ops.pad != 0, (im.flags & TERM_CHECK2) != 0);
+          if (pass == 0) {
+            if (im.keyA != kNoKey) boundA = bound_fma((float)key_l2[im.keyA], nb, boundA);
+            if (pair && im.keyB != kNoKey) boundB = bound_fma((float)key_l2[im.keyB], nb, boundB);
+          }
+          const bool feedsA = im.keyA != kNoKey;
+          const bool feedsB = pair && last && im.keyB != kNoKey;
+          const int pi0 = pass == 0 ? 0 : 2, pi1 = pass == 0 ? 2 : 3;
+#pragma unroll 1
+          for (int pi = pi0; pi < pi1; ++pi) {
+            RZK_STEP_PRIORITY();
+            const PrimeConsts pc = T.pc[pi];
+            const uint32_t* __restrict__ twf = tw_all + (size_t)(2 * pi) * kTableLen;
+            uint32_t x[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) x[e] = lift(v[e], pc);
+            wave_fwd<LOGN, TM>(x, ln, lds, twf, pc);
+            if (feedsA) {
+              const uint4* __restrict__ kpA = reinterpret_cast<const uint4*>(key_ntt + ((size_t)im.keyA * kKeyImages + pi) * N);
+              uint32_t kreg[E];
+#pragma unroll
+              for (int g = 0; g < E / 4; ++g) {
+                const uint4 kv = kpA[G::key4(ln, g)];
+                kreg[4 * g] = kv.x, kreg[4 * g + 1] = kv.y, kreg[4 * g + 2] = kv.z, kreg[4 * g + 3] = kv.w;
+              }
+              // (parking leaves x untouched: row B's product below is formed from the same transform)
+              if (pi == 0) mac_park<LOGN, false, TM>(x, kreg, im.signA < 0, P4, ln, !haveA, pc);
+              else mac_park<LOGN, false, TM>(x, kreg, im.signA < 0, reinterpret_cast<uint4*>(st + (pi == 1 ? 0 : 3) * N), ln, !haveA, pc);
+            }
+            if (feedsB) {
+              const uint4* __restrict__ kpB = reinterpret_cast<const uint4*>(key_ntt + ((size_t)im.keyB * kKeyImages + pi) * N);
+              uint32_t kbr[E];
+#pragma unroll
+              for (int g = 0; g < E / 4; ++g) {
+                const uint4 kv = kpB[G::key4(ln, g)];
+                kbr[4 * g] = kv.x, kbr[4 * g + 1] = kv.y, kbr[4 * g + 2] = kv.z, kbr[4 * g + 3] = kv.w;
+              }
+              mac_park<LOGN, false, TM>(x, kbr, im.signB < 0, reinterpret_cast<uint4*>(st + (pi == 0 ? 1 : (pi == 1 ? 2 : 5)) * N), ln, true, pc);
+            }
+          }
+          haveA = haveA || feedsA;
+        }
+        if (pass == 0) {
+          if (fault) input_fault(ops, flags, bo, lane);
+          np = primes_for(boundA > boundB ? boundA : boundB, T);
+          np = np < 2 ? 2 : np;
+        }
+      }
+      // ---- the rows: inverse transforms back to back, reconstruction in registers
+#pragma unroll 1
+      for (uint32_t r = 0; r < (pair ? 2u : 1u); ++r) {
+        int li = lane;
+        RZK_OPAQUE(li);
+        const bool have = r == 1 || haveA;
+        uint32_t u[E];     // the row's value mod q
+        if (!have) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) u[e] = 0;
+        } else {
+          uint32_t a[E];
+          if (r == 0) unpark<LOGN, TM>(a, const_cast<const uint4*>(P4), li);
+          else unpark<LOGN, TM>(a, reinterpret_cast<const uint4*>(st + 1 * N), li);
+          RZK_STEP_PRIORITY();
+          wave_inv<LOGN, TM>(a, li, lds, tw_all + (size_t)(2 * 0 + 1) * kTableLen, T.pc[0]);
+          if (np == 2) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) u[e] = crt2_digit0(a[e], T.pc);
+            unpark<LOGN, TM>(a, reinterpret_cast<const uint4*>(st + (r == 0 ? 0 : 2) * N), li);
+            RZK_STEP_PRIORITY();
+            wave_inv<LOGN, TM>(a, li, lds, tw_all + (size_t)(2 * 1 + 1) * kTableLen, T.pc[1]);
+#pragma unroll
+            for (int e = 0; e < E; ++e) u[e] = crt2_zq(a[e], u[e], T.pc, T.crt);
+          } else {   // three primes: the offset form, words A and B in registers
+            uint32_t wb[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) u[e] = crt_fold0(a[e], 3, T.pc, T.crt);
+            unpark<LOGN, TM>(a, reinterpret_cast<const uint4*>(st + (r == 0 ? 0 : 2) * N), li);
+            RZK_STEP_PRIORITY();
+            wave_inv<LOGN, TM>(a, li, lds, tw_all + (size_t)(2 * 1 + 1) * kTableLen, T.pc[1]);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+              wb[e] = 0;
+              crt_fold1(a[e], 3, T.pc, T.crt, u[e], wb[e]);
+            }
+            unpark<LOGN, TM>(a, reinterpret_cast<const uint4*>(st + (r == 0 ? 3 : 5) * N), li);
+            RZK_STEP_PRIORITY();
+            wave_inv<LOGN, TM>(a, li, lds, tw_all + (size_t)(2 * 2 + 1) * kTableLen, T.pc[2]);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+              crt_fold2(a[e], T.pc, T.crt, u[e], wb[e]);
+              u[e] = crt_finish_zq(u[e], 3, T.crt);
+            }
+          }
+        }
+        finish_row<LOGN, 16, TM>(u, prog, table_load(&prog->rows[r ? un.rowB : un.rowA]), ops, b, bo, lane, T, flags,
+                                 (has_shift && r == 0) ? st_sh : nullptr);
+      }
+    }
+  }
+#undef RZK_STEP_PRIORITY
+#if RZK_STAMPS
+  if (lane == 0) {
+    const uint64_t stamp1 = __builtin_amdgcn_s_memrealtime();
+    uint32_t hwid;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    uint32_t* o = st + kScratchLines * N;
+    o[0] = (uint32_t)stamp0, o[1] = (uint32_t)(stamp0 >> 32), o[2] = (uint32_t)stamp1, o[3] = (uint32_t)(stamp1 >> 32);
+    o[4] = hwid, o[5] = xcc, o[6] = blockIdx.x, o[7] = wave;
+    const uint64_t cyc1 = __builtin_amdgcn_s_memtime();
+    o[8] = (uint32_t)(cyc1 - cyc0);
+    o[9] = o[10] = o[11] = o[12] = o[13] = o[14] = 0;
   }
 #endif
 }
@@ -2538,6 +2807,25 @@ static int launch_units_t(const LaunchCfg& cfg, const Program* d_prog, const Wav
 }
 
 template <int LOGN, bool HAS_SHIFT, class TM = WaveTeam>
+static int launch_units_io_t(const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, const Operands& ops,
+                             const uint32_t* d_key_ntt, const double* d_key_l2, const DevTables* T, const uint32_t* d_tw,
+                             uint32_t* d_scratch, uint8_t* d_flags, uint32_t ntasks, uint32_t upt, uint32_t tpe, uint32_t wpt) {
+  using G = Geo<LOGN, TM::LL>;
+  constexpr int TPB = TM::kTeamsPerBlock;
+  const size_t lds = TPB * (size_t)(G::LDS_WORDS + G::N) * sizeof(uint32_t);   // per team: transposition slab + P
+  if (lds > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&unit_io_kernel<LOGN, HAS_SHIFT, TM>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const unsigned grid = grid_for(ntasks, cfg.num_cus, TPB, 8);
+  hipLaunchKernelGGL((unit_io_kernel<LOGN, HAS_SHIFT, TM>), dim3(grid), dim3(TPB << TM::LL), lds, (hipStream_t)cfg.stream,
+                     d_prog, d_wp, ops, d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks, upt, tpe, wpt);
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int LOGN, bool HAS_SHIFT, class TM = WaveTeam>
 static int launch_rows_t(const LaunchCfg& cfg, const Program* d_prog, const Operands& ops, const uint32_t* d_key_ntt,
                          const double* d_key_l2, const DevTables* T, const uint32_t* d_tw, uint32_t* d_scratch,
                          uint8_t* d_flags, uint32_t ntasks) {
@@ -2585,6 +2873,16 @@ int launch_units(int logn, const LaunchCfg& cfg, const Program* d_prog, const Wa
   const uint32_t ntasks = (uint32_t)(batch * tpe);
   const uint32_t wpt = (work_per_entry + tpe - 1) / tpe;   // transforms per task (estimate, for the progress priorities)
 #define RZK_UNIT_ARGS cfg, d_prog, d_wp, ops, d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks, units_per_task, tpe, wpt
+  if (!has_vec && cfg.unit_io) {   // key-product programs: every operand read once (unit_io_kernel)
+    switch (logn) {
+      case 9: return has_shift ? launch_units_io_t<9, true>(RZK_UNIT_ARGS) : launch_units_io_t<9, false>(RZK_UNIT_ARGS);
+      case 10: return has_shift ? launch_units_io_t<10, true>(RZK_UNIT_ARGS) : launch_units_io_t<10, false>(RZK_UNIT_ARGS);
+      case 11:
+        if (has_shift) return -1;
+        return cfg.pair_poly ? launch_units_io_t<11, false, PairTeam>(RZK_UNIT_ARGS) : launch_units_io_t<11, false>(RZK_UNIT_ARGS);
+    }
+    return -1;
+  }
 #define RZK_UNIT_CASE(L)                                                                                            \
   case L:                                                                                                           \
     if (has_shift)                                                                                                  \

@@ -24,6 +24,54 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ---- streaming accesses -------------------------------------------------------------------------------------------
+// Coefficient slabs are read once or twice and written once per launch: RZK_NT_LD / RZK_NT_ST select the non-temporal
+// cache policy for them (so that they do not push the resident key, the twiddles and the teams' scratch lines out of
+// L2).  Tuning knobs; see DESIGN.md §6 for what was measured.
+#ifndef RZK_NT_LD
+#define RZK_NT_LD 0
+#endif
+#ifndef RZK_NT_ST
+#define RZK_NT_ST 1   // measured (Open N=1024, A/B of prebuilt libraries): stores nt +1.5 % (response 78.3 -> 76.0 us); loads nt -1.5 %
+#endif
+template <class Tp>
+__device__ __forceinline__ Tp ld_stream(const Tp* p) {
+#if RZK_NT_LD
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ longlong2 ld_stream(const longlong2* p) {
+#if RZK_NT_LD
+  typedef long long v2ll __attribute__((ext_vector_type(2)));
+  const v2ll t = __builtin_nontemporal_load(reinterpret_cast<const v2ll*>(p));
+  longlong2 r;
+  r.x = t.x, r.y = t.y;
+  return r;
+#else
+  return *p;
+#endif
+}
+template <class Tp>
+__device__ __forceinline__ void st_stream(Tp* p, Tp v) {
+#if RZK_NT_ST
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ void st_stream(int4* p, int4 v) {
+#if RZK_NT_ST
+  typedef int v4i __attribute__((ext_vector_type(4)));
+  v4i t;
+  t.x = v.x, t.y = v.y, t.z = v.z, t.w = v.w;
+  __builtin_nontemporal_store(t, reinterpret_cast<v4i*>(p));
+#else
+  *p = v;
+#endif
+}
+
 // ---- wave reductions ------------------------------------------------------------------------------------
 // Butterfly inside the 16-lane rows with DPP operand modifiers (xor 1, xor 2, half-row mirror, row mirror), then the
 // two row broadcasts of GFX9 (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3): six VALU instructions
@@ -399,7 +447,7 @@ __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict
       int32_t v[G::E];
       uint32_t bad = 0;
 #pragma unroll
-      for (int e = 0; e < G::E; ++e) v[e] = trusted ? (int32_t)src[G::j_p1(lane, e)] : canon_lo(src[G::j_p1(lane, e)], qhalf, bad);
+      for (int e = 0; e < G::E; ++e) v[e] = trusted ? (int32_t)ld_stream(src + G::j_p1(lane, e)) : canon_lo(ld_stream(src + G::j_p1(lane, e)), qhalf, bad);
       uint64_t sum = 0;
       uint32_t mxa = 0;
 #pragma unroll
@@ -438,7 +486,7 @@ __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict
         uint32_t y[H];
 #pragma unroll
         for (int e2 = 0; e2 < H; ++e2) {
-          const int64_t c = src[(size_t)(h * H + e2) * G::LANES + lane];
+          const int64_t c = ld_stream(src + (size_t)(h * H + e2) * G::LANES + lane);
           const int32_t v = trusted ? (int32_t)c : canon_lo_mx(c, qhalf, bad, mx);
           const float f = (float)v;
           part = __builtin_fmaf(f, f, part);
@@ -454,7 +502,7 @@ __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict
     } else if (trusted) {
 #pragma unroll
       for (int e = 0; e < G::E; ++e) {
-        const int32_t v = (int32_t)src[G::j_p1(lane, e)];
+        const int32_t v = (int32_t)ld_stream(src + G::j_p1(lane, e));
         const float f = (float)v;
         part = __builtin_fmaf(f, f, part);
         x[e] = lift(v, pc);
@@ -463,7 +511,7 @@ __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict
       uint32_t bad = 0, mx = 0;
 #pragma unroll
       for (int e = 0; e < G::E; ++e) {
-        const int32_t v = canon_lo_mx(src[G::j_p1(lane, e)], qhalf, bad, mx);
+        const int32_t v = canon_lo_mx(ld_stream(src + G::j_p1(lane, e)), qhalf, bad, mx);
         const float f = (float)v;
         part = __builtin_fmaf(f, f, part);
         x[e] = lift(v, pc);
@@ -487,7 +535,7 @@ __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict
     }
   } else {
 #pragma unroll
-    for (int e = 0; e < G::E; ++e) x[e] = lift((int32_t)src[G::j_p1(lane, e)], pc);
+    for (int e = 0; e < G::E; ++e) x[e] = lift((int32_t)ld_stream(src + G::j_p1(lane, e)), pc);
   }
 }
 
@@ -529,12 +577,12 @@ __device__ __forceinline__ void load_pairs(int32_t* v, const int64_t* __restrict
   if (trusted) {
 #pragma unroll
     for (int g = 0; g < S::G; ++g) {
-      const longlong2 t = p[g * 64 + lane];
+      const longlong2 t = ld_stream(p + g * 64 + lane);
       v[2 * g] = (int32_t)t.x, v[2 * g + 1] = (int32_t)t.y;
     }
   } else {
 #pragma unroll
-    for (int g = 0; g < S::G; ++g) canon_pair(p[g * 64 + lane], qhalf, bad, mx, v[2 * g], v[2 * g + 1]);   // coefficients g*128 + 2*lane, +1
+    for (int g = 0; g < S::G; ++g) canon_pair(ld_stream(p + g * 64 + lane), qhalf, bad, mx, v[2 * g], v[2 * g + 1]);   // coefficients g*128 + 2*lane, +1
   }
 }
 
@@ -583,7 +631,7 @@ __device__ __forceinline__ void shift_fill_from(const int64_t* __restrict__ pv, 
       const longlong2* __restrict__ p = reinterpret_cast<const longlong2*>(pv) + (size_t)h * (H / 2) * 64;
 #pragma unroll
       for (int g = 0; g < H / 2; ++g) {
-        const longlong2 t = p[g * 64 + lane];   // coefficients (h*H/2 + g)*128 + 2*lane, +1
+        const longlong2 t = ld_stream(p + g * 64 + lane);   // coefficients (h*H/2 + g)*128 + 2*lane, +1
         if (canon) {
           canon_pair(t, qhalf, bad, mx, vh[2 * g], vh[2 * g + 1]);
         } else {
@@ -826,10 +874,10 @@ __device__ __forceinline__ void add_chunk(uint32_t* u, const AddTerm ad, uint32_
   int32_t av[CH];
   if (trusted) {
 #pragma unroll
-    for (int i = 0; i < CH; ++i) av[i] = (int32_t)src[G::j_p1(lane, e0 + i)];
+    for (int i = 0; i < CH; ++i) av[i] = (int32_t)ld_stream(src + G::j_p1(lane, e0 + i));
   } else {
 #pragma unroll
-    for (int i = 0; i < CH; ++i) av[i] = canon_lo_mx(src[G::j_p1(lane, e0 + i)], qhalf, in_bad, in_mx);
+    for (int i = 0; i < CH; ++i) av[i] = canon_lo_mx(ld_stream(src + G::j_p1(lane, e0 + i)), qhalf, in_bad, in_mx);
   }
   if (ad.op & (ADD_CHECK | ADD_CHECK2)) {
     float sq = 0.f;
@@ -890,7 +938,7 @@ __device__ __forceinline__ void row_epilogue(const Program* __restrict__ prog, c
     if (row.mode == MODE_STORE) {
       int64_t* __restrict__ dst = const_cast<int64_t*>(operand_ptr(ops, row.out_op, row.out_off, b, bo, N));
 #pragma unroll
-      for (int i = 0; i < CH; ++i) dst[G::j_p1(lane, e0 + i)] = center_from_zq(u[i], T.crt);
+      for (int i = 0; i < CH; ++i) st_stream(dst + G::j_p1(lane, e0 + i), center_from_zq(u[i], T.crt));
     } else {
 #pragma unroll
       for (int i = 0; i < CH; ++i) nz |= (u[i] != 0);
@@ -1142,7 +1190,7 @@ __device__ __forceinline__ void finish_row(uint32_t* u, const Program* __restric
     if (row.mode == MODE_STORE) {
       int64_t* __restrict__ dst = const_cast<int64_t*>(operand_ptr(ops, row.out_op, row.out_off, b, bo, N));
 #pragma unroll
-      for (int i = 0; i < CH; ++i) dst[G::j_p1(lane, e0 + i)] = center_from_zq(u[e0 + i], T.crt);
+      for (int i = 0; i < CH; ++i) st_stream(dst + G::j_p1(lane, e0 + i), center_from_zq(u[e0 + i], T.crt));
     } else {
 #pragma unroll
       for (int i = 0; i < CH; ++i) nz |= (u[e0 + i] != 0);
@@ -1840,12 +1888,12 @@ shift_row_kernel(const Program* __restrict__ prog, const Operands ops, const Dev
         if (trusted) {
 #pragma unroll
           for (int g = 0; g < GC; ++g) {
-            const longlong2 t = p[g * 64];
+            const longlong2 t = ld_stream(p + g * 64);
             av[2 * g] = (int32_t)t.x, av[2 * g + 1] = (int32_t)t.y;
           }
         } else {
 #pragma unroll
-          for (int g = 0; g < GC; ++g) canon_pair(p[g * 64], qhalf, in_bad, in_mx, av[2 * g], av[2 * g + 1]);
+          for (int g = 0; g < GC; ++g) canon_pair(ld_stream(p + g * 64), qhalf, in_bad, in_mx, av[2 * g], av[2 * g + 1]);
         }
         if (ad.sign >= 0) {
 #pragma unroll
@@ -1861,7 +1909,7 @@ shift_row_kernel(const Program* __restrict__ prog, const Operands ops, const Dev
 #pragma unroll
         for (int g = 0; g < GC; ++g) {
           const int64_t c0 = center_from_zq(r[2 * g], T.crt), c1 = center_from_zq(r[2 * g + 1], T.crt);
-          dst[g * 64] = make_int4((int32_t)c0, (int32_t)(c0 >> 32), (int32_t)c1, (int32_t)(c1 >> 32));
+          st_stream(dst + g * 64, make_int4((int32_t)c0, (int32_t)(c0 >> 32), (int32_t)c1, (int32_t)(c1 >> 32)));
         }
       } else {
 #pragma unroll

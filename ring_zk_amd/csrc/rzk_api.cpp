@@ -101,7 +101,8 @@ struct rzk_ctx {
   bool use_groups = true;
   uint32_t units_per_task = 0;         // 0 = automatic (RZK_UPT overrides, tuning)
   bool vec_rows = true;                // programs with vector x vector products: row_kernel (RZK_VEC_ROWS=0: unit_kernel)
-  bool unit_io = false;                // key-product programs through unit_io_kernel (every operand read once; RZK_UNIT_IO=1): measured slower, see DESIGN.md
+  bool unit_io = false;                // key-product programs through unit_io_kernel (every operand read once): where its sums park in
+                                       // LDS (N = 512); RZK_UNIT_IO=0 / 1 forces unit_kernel / unit_io_kernel
   bool pair_poly = true;               // N = 2048: two wavefronts per polynomial (RZK_PAIR_POLY=0: one, the round-2 kernels)
   bool trusted = false;                // rzk_ctx_trust_device_outputs: skip the canonical test of loaded coefficients
   bool use_pairs = true;               // unit_kernel: pair rows that share their last operand (RZK_PAIRS=0 turns it off, tuning)
@@ -1069,6 +1070,7 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
   if (const char* e = std::getenv("RZK_UPT")) c->units_per_task = (uint32_t)std::atoi(e);
   if (const char* e = std::getenv("RZK_VEC_ROWS")) c->vec_rows = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_PAIR_POLY")) c->pair_poly = std::atoi(e) != 0;
+  c->unit_io = c->logn == 9;
   if (const char* e = std::getenv("RZK_UNIT_IO")) c->unit_io = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_BLOCK_MIN_LOGN")) c->block_min_logn = (uint32_t)std::atoi(e);   // 12 = never
 

@@ -1501,8 +1501,31 @@ __device__ __forceinline__ void unpark(uint32_t* a, P4T P4, int lane) {
   }
 }
 
+// Where the sums park between items (LDS budget: 10 KiB per wavefront at 4 waves per SIMD):
+//   N = 512   slab 2.1 KiB + A/p0, A/p1, B/p0 (2 KiB each) = 8.1 KiB: only B/p1 and the third-prime sums use global
+//             lines.  This is the default kernel of key-product programs at N = 512 (Open cycle 27.1 -> 29.6 M proofs/s).
+//   N >= 1024 A/p0 in LDS, everything else in global lines: slower than unit_kernel (Open N = 1024: commit 145 vs 129 us;
+//             a variant with a half-size transposition slab and both A sums in LDS: 139-146 us — the two-round
+//             transpositions need ~127 VGPRs before any key entry can be requested ahead of a transform, see
+//             DESIGN.md §6), so it is reachable only through RZK_UNIT_IO=1 (tests).
+#ifndef RZK_IO_B0_LDS
+#define RZK_IO_B0_LDS 1
+#endif
+#ifndef RZK_IO_MIN_WAVES
+#define RZK_IO_MIN_WAVES (TM::LL == 7 || LOGN == 10 ? 4 : 1)   // 16 coefficients per thread: 4 waves per SIMD
+#endif
+template <int LOGN, int LL>
+struct IoCfg {
+  static constexpr bool P1_FULL = LOGN == 9;                      // A / prime 1 in an LDS buffer
+  static constexpr bool B0_LDS = LOGN == 9 && RZK_IO_B0_LDS;      // B / prime 0 in an LDS buffer
+  static constexpr int N = 1 << LOGN;
+  static constexpr int SLAB = Geo<LOGN, LL>::LDS_WORDS;
+  static constexpr int OFF_P1 = SLAB + N;
+  static constexpr int OFF_B0 = OFF_P1 + (P1_FULL ? N : 0);
+  static constexpr int WORDS = OFF_B0 + (B0_LDS ? N : 0);         // LDS words per team
+};
 template <int LOGN, bool HAS_SHIFT, class TM = WaveTeam>
-__global__ void __launch_bounds__(TM::kTeamsPerBlock << TM::LL, (TM::LL == 7 || LOGN == 10 ? 4 : 1))   // 16 coefficients per thread: 4 waves per SIMD
+__global__ void __launch_bounds__(TM::kTeamsPerBlock << TM::LL, RZK_IO_MIN_WAVES)
 unit_io_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp, const Operands ops,
                const uint32_t* __restrict__ key_ntt, const double* __restrict__ key_l2, const DevTables* __restrict__ Tp,
                const uint32_t* __restrict__ tw_all, uint32_t* __restrict__ scratch, uint8_t* __restrict__ flags,
@@ -1516,8 +1539,14 @@ unit_io_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__
   const int lane = threadIdx.x & (G::LANES - 1);
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> TM::LL);
   constexpr int TPB = TM::kTeamsPerBlock;
-  uint32_t* lds = smem + wave * (G::LDS_WORDS + N);             // transposition slab, then P
-  uint4* P4 = reinterpret_cast<uint4*>(lds + G::LDS_WORDS);
+  // Where LDS allows (N = 512: 6.2 KiB per wavefront) the prime-1 sum of row A parks in a second LDS buffer instead of
+  // a global line (IO_P1_LDS)
+  using IO = IoCfg<LOGN, TM::LL>;
+  constexpr bool P1L = IO::P1_FULL, B0L = IO::B0_LDS;
+  uint32_t* lds = smem + wave * IO::WORDS;                                          // transposition slab, then the parking buffers
+  uint4* P4 = reinterpret_cast<uint4*>(lds + IO::SLAB);                             // A / prime 0
+  uint4* P41 = reinterpret_cast<uint4*>(lds + IO::OFF_P1);                          // A / prime 1   (P1L)
+  uint4* PB0 = reinterpret_cast<uint4*>(lds + IO::OFF_B0);                          // B / prime 0   (B0L)
   uint32_t* st = scratch + ((size_t)blockIdx.x * TPB + wave) * (size_t)(kScratchLines * N + 16);
   uint32_t* st_sh = st + 4 * N;
 #if RZK_STAMPS
@@ -1594,50 +1623,96 @@ unit_io_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__
           int ln = lane;
           RZK_OPAQUE(ln);
           const Item im = table_load(&wp->items[un.item0 + it]);
-          int32_t v[E];
-          float nb = 0.f;
-          bool below = true;
+          const int64_t* __restrict__ src = operand_ptr(ops, im.b_op, im.b_off, b, bo, N);
           const bool chk = pass == 0 && (im.flags & (TERM_CHECK | TERM_CHECK2));
-          load_measure<LOGN, TM>(v, operand_ptr(ops, im.b_op, im.b_off, b, bo, N), ln, pass == 0, nb, chk, ops.norm_limit, below,
-                                 qhalf, trusted, fault);
-          if (chk && !below && (lane & 63) == 0) fail_check(flags + bo, ops.pad != 0, (im.flags & TERM_CHECK2) != 0);
-          if (pass == 0) {
-            if (im.keyA != kNoKey) boundA = bound_fma((float)key_l2[im.keyA], nb, boundA);
-            if (pair && im.keyB != kNoKey) boundB = bound_fma((float)key_l2[im.keyB], nb, boundB);
-          }
           const bool feedsA = im.keyA != kNoKey;
           const bool feedsB = pair && last && im.keyB != kNoKey;
           const int pi0 = pass == 0 ? 0 : 2, pi1 = pass == 0 ? 2 : 3;
+          // The operand's one trip from HBM: canonical test, norm measurement, norm mark (first pass).  With 8
+          // coefficients per lane the low words simply stay in registers for the second prime (RETAIN); with 16 or
+          // more they are read again — microseconds later, out of L2 — because keeping them through a transform costs
+          // the registers that hold the kernel at 4 waves per SIMD.
+          constexpr bool RETAIN = E <= 8;
+          int32_t vkeep[RETAIN ? E : 1];
+          if (RETAIN) {
+            float nb = 0.f;
+            bool below = true;
+            load_measure<LOGN, TM>(vkeep, src, ln, pass == 0, nb, chk, ops.norm_limit, below, qhalf, trusted, fault);
+            if (chk && !below && (lane & 63) == 0) fail_check(flags + bo, ops.pad != 0, (im.flags & TERM_CHECK2) != 0);
+            if (pass == 0) {
+              if (feedsA) boundA = bound_fma((float)key_l2[im.keyA], nb, boundA);
+              if (pair && im.keyB != kNoKey) boundB = bound_fma((float)key_l2[im.keyB], nb, boundB);
+            }
+          }
 #pragma unroll 1
           for (int pi = pi0; pi < pi1; ++pi) {
             RZK_STEP_PRIORITY();
+            RZK_OPAQUE(ln);   // per transform: lane-dependent addresses must not be hoisted out of this loop (30 VGPRs)
             const PrimeConsts pc = T.pc[pi];
             const uint32_t* __restrict__ twf = tw_all + (size_t)(2 * pi) * kTableLen;
             uint32_t x[E];
+            if (RETAIN) {
 #pragma unroll
-            for (int e = 0; e < E; ++e) x[e] = lift(v[e], pc);
-            wave_fwd<LOGN, TM>(x, ln, lds, twf, pc);
-            if (feedsA) {
-              const uint4* __restrict__ kpA = reinterpret_cast<const uint4*>(key_ntt + ((size_t)im.keyA * kKeyImages + pi) * N);
-              uint32_t kreg[E];
+              for (int e = 0; e < E; ++e) x[e] = lift(vkeep[RETAIN ? e : 0], pc);
+            } else if (pi == pi0) {
+              int32_t v[E];
+              float nb = 0.f;
+              bool below = true;
+              load_measure<LOGN, TM>(v, src, ln, pass == 0, nb, chk, ops.norm_limit, below, qhalf, trusted, fault);
+              if (chk && !below && (lane & 63) == 0) fail_check(flags + bo, ops.pad != 0, (im.flags & TERM_CHECK2) != 0);
+              if (pass == 0) {
+                if (feedsA) boundA = bound_fma((float)key_l2[im.keyA], nb, boundA);
+                if (pair && im.keyB != kNoKey) boundB = bound_fma((float)key_l2[im.keyB], nb, boundB);
+              }
+#pragma unroll
+              for (int e = 0; e < E; ++e) x[e] = lift(v[e], pc);
+            } else {
+              const int32_t* __restrict__ lo32 = reinterpret_cast<const int32_t*>(src);
+#pragma unroll
+              for (int e = 0; e < E; ++e) x[e] = lift(lo32[2 * G::j_p1(ln, e)], pc);
+            }
+            // (requesting row A's key entry before the transform, as unit_kernel does, does not pay here:)
+            constexpr bool EARLY = false;   // (measured at N = 512: 42.3 us against 40.4 for the verify rows; at N = 1024 the entry
+                                            //  would cost 30 VGPRs across the transform)
+            const uint4* __restrict__ kpA = reinterpret_cast<const uint4*>(key_ntt + ((size_t)(feedsA ? im.keyA : 0) * kKeyImages + pi) * N);
+            uint32_t kreg[E];
+            if (EARLY && feedsA) {
+              // ... but not ahead of the operand itself: the request is tied to the last lifted coefficient, or the scheduler
+              // issues it first and the entry sits in registers next to the 64-bit loads of the operand (+32 VGPRs)
+              int lk = ln;
+              asm volatile("" : "+v"(lk) : "v"(x[E - 1]));
 #pragma unroll
               for (int g = 0; g < E / 4; ++g) {
-                const uint4 kv = kpA[G::key4(ln, g)];
+                const uint4 kv = kpA[G::key4(lk, g)];
                 kreg[4 * g] = kv.x, kreg[4 * g + 1] = kv.y, kreg[4 * g + 2] = kv.z, kreg[4 * g + 3] = kv.w;
+              }
+            }
+            wave_fwd<LOGN, TM>(x, ln, lds, twf, pc);
+            if (feedsA) {
+              if (!EARLY) {
+#pragma unroll
+                for (int g = 0; g < E / 4; ++g) {
+                  const uint4 kv = kpA[G::key4(ln, g)];
+                  kreg[4 * g] = kv.x, kreg[4 * g + 1] = kv.y, kreg[4 * g + 2] = kv.z, kreg[4 * g + 3] = kv.w;
+                }
               }
               // (parking leaves x untouched: row B's product below is formed from the same transform)
               if (pi == 0) mac_park<LOGN, false, TM>(x, kreg, im.signA < 0, P4, ln, !haveA, pc);
+              else if (P1L && pi == 1) mac_park<LOGN, false, TM>(x, kreg, im.signA < 0, P41, ln, !haveA, pc);
               else mac_park<LOGN, false, TM>(x, kreg, im.signA < 0, reinterpret_cast<uint4*>(st + (pi == 1 ? 0 : 3) * N), ln, !haveA, pc);
             }
             if (feedsB) {
               const uint4* __restrict__ kpB = reinterpret_cast<const uint4*>(key_ntt + ((size_t)im.keyB * kKeyImages + pi) * N);
               uint32_t kbr[E];
+              int lb = ln;
+              asm volatile("" : "+v"(lb));   // row B's entry is requested HERE, not ahead of the transform (16 VGPRs)
 #pragma unroll
               for (int g = 0; g < E / 4; ++g) {
-                const uint4 kv = kpB[G::key4(ln, g)];
+                const uint4 kv = kpB[G::key4(lb, g)];
                 kbr[4 * g] = kv.x, kbr[4 * g + 1] = kv.y, kbr[4 * g + 2] = kv.z, kbr[4 * g + 3] = kv.w;
               }
-              mac_park<LOGN, false, TM>(x, kbr, im.signB < 0, reinterpret_cast<uint4*>(st + (pi == 0 ? 1 : (pi == 1 ? 2 : 5)) * N), ln, true, pc);
+              if (B0L && pi == 0) mac_park<LOGN, false, TM>(x, kbr, im.signB < 0, PB0, ln, true, pc);
+              else mac_park<LOGN, false, TM>(x, kbr, im.signB < 0, reinterpret_cast<uint4*>(st + (pi == 0 ? 1 : (pi == 1 ? 2 : 5)) * N), ln, true, pc);
             }
           }
           haveA = haveA || feedsA;
@@ -1661,14 +1736,18 @@ unit_io_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__
         } else {
           uint32_t a[E];
           if (r == 0) unpark<LOGN, TM>(a, const_cast<const uint4*>(P4), li);
+          else if (B0L) unpark<LOGN, TM>(a, const_cast<const uint4*>(PB0), li);
           else unpark<LOGN, TM>(a, reinterpret_cast<const uint4*>(st + 1 * N), li);
           RZK_STEP_PRIORITY();
+          RZK_OPAQUE(li);
           wave_inv<LOGN, TM>(a, li, lds, tw_all + (size_t)(2 * 0 + 1) * kTableLen, T.pc[0]);
           if (np == 2) {
 #pragma unroll
             for (int e = 0; e < E; ++e) u[e] = crt2_digit0(a[e], T.pc);
-            unpark<LOGN, TM>(a, reinterpret_cast<const uint4*>(st + (r == 0 ? 0 : 2) * N), li);
+            if (P1L && r == 0) unpark<LOGN, TM>(a, const_cast<const uint4*>(P41), li);
+            else unpark<LOGN, TM>(a, reinterpret_cast<const uint4*>(st + (r == 0 ? 0 : 2) * N), li);
             RZK_STEP_PRIORITY();
+            RZK_OPAQUE(li);
             wave_inv<LOGN, TM>(a, li, lds, tw_all + (size_t)(2 * 1 + 1) * kTableLen, T.pc[1]);
 #pragma unroll
             for (int e = 0; e < E; ++e) u[e] = crt2_zq(a[e], u[e], T.pc, T.crt);
@@ -1676,8 +1755,10 @@ unit_io_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__
             uint32_t wb[E];
 #pragma unroll
             for (int e = 0; e < E; ++e) u[e] = crt_fold0(a[e], 3, T.pc, T.crt);
-            unpark<LOGN, TM>(a, reinterpret_cast<const uint4*>(st + (r == 0 ? 0 : 2) * N), li);
+            if (P1L && r == 0) unpark<LOGN, TM>(a, const_cast<const uint4*>(P41), li);
+            else unpark<LOGN, TM>(a, reinterpret_cast<const uint4*>(st + (r == 0 ? 0 : 2) * N), li);
             RZK_STEP_PRIORITY();
+            RZK_OPAQUE(li);
             wave_inv<LOGN, TM>(a, li, lds, tw_all + (size_t)(2 * 1 + 1) * kTableLen, T.pc[1]);
 #pragma unroll
             for (int e = 0; e < E; ++e) {
@@ -1686,6 +1767,7 @@ unit_io_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__
             }
             unpark<LOGN, TM>(a, reinterpret_cast<const uint4*>(st + (r == 0 ? 3 : 5) * N), li);
             RZK_STEP_PRIORITY();
+            RZK_OPAQUE(li);
             wave_inv<LOGN, TM>(a, li, lds, tw_all + (size_t)(2 * 2 + 1) * kTableLen, T.pc[2]);
 #pragma unroll
             for (int e = 0; e < E; ++e) {
@@ -2860,7 +2942,7 @@ static int launch_units_io_t(const LaunchCfg& cfg, const Program* d_prog, const 
                              uint32_t* d_scratch, uint8_t* d_flags, uint32_t ntasks, uint32_t upt, uint32_t tpe, uint32_t wpt) {
   using G = Geo<LOGN, TM::LL>;
   constexpr int TPB = TM::kTeamsPerBlock;
-  const size_t lds = TPB * (size_t)(G::LDS_WORDS + G::N) * sizeof(uint32_t);   // per team: transposition slab + P
+  const size_t lds = TPB * (size_t)IoCfg<LOGN, TM::LL>::WORDS * sizeof(uint32_t);   // per team: slab + parking buffers
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&unit_io_kernel<LOGN, HAS_SHIFT, TM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -223,6 +223,14 @@ def test_config5_shape_vs_oracle(torch_mod):
     dict(N=2048, shape=(2, 5, 2), V=2, env={"RZK_PAIR_POLY": 0, "RZK_VEC_ROWS": 0, "RZK_BLOCK_MIN_LOGN": 12}),
     # ... and two per polynomial without row blocks: grouped rows fall to the unit kernel's pairs
     dict(N=2048, shape=(2, 5, 2), V=3, env={"RZK_BLOCK_MIN_LOGN": 12}),
+    # unit_io_kernel (operands read once) where it is not the default: global parking lines, one- and two-wavefront teams;
+    # and unit_kernel where unit_io_kernel is the default
+    dict(N=1024, shape=(1, 3, 1), V=2, env={"RZK_UNIT_IO": 1}),
+    dict(N=1024, shape=(2, 5, 2), V=2, env={"RZK_UNIT_IO": 1, "RZK_ROW_GROUPS": 0}),
+    dict(N=2048, shape=(1, 3, 1), V=2, env={"RZK_UNIT_IO": 1}),
+    dict(N=2048, shape=(2, 5, 2), V=2, env={"RZK_UNIT_IO": 1, "RZK_BLOCK_MIN_LOGN": 12}),
+    dict(N=512, shape=(2, 5, 2), V=2, env={"RZK_UNIT_IO": 0, "RZK_ROW_GROUPS": 0}),
+    dict(N=512, shape=(2, 5, 2), V=2, env={"RZK_ROW_GROUPS": 0}),
 ])
 def test_forced_kernel_paths_vs_oracle(torch_mod, cfg):
     N, (n, k, l), V = cfg["N"], cfg["shape"], cfg["V"]
@@ -234,15 +242,19 @@ def test_forced_kernel_paths_vs_oracle(torch_mod, cfg):
 
 
 # ---- operands of very different sizes in one batch: the per-proof prime count (1, 2 or 3) is decided from the norms
+@pytest.mark.parametrize("io", [None, 0, 1])
 @pytest.mark.parametrize("upt", [0, 64])
 @pytest.mark.parametrize("N", [512, 1024, 2048])
-def test_prime_count_per_proof_vs_oracle(torch_mod, N, upt):
+def test_prime_count_per_proof_vs_oracle(torch_mod, N, upt, io):
     """Randomness of six different magnitudes in one batch — ternary, two sparse spikes, constant 8, one large pair, a
     single -1, full range — so that neighbouring proofs of one launch need 1, 2 and 3 auxiliary primes; upt = 64 walks
     all units of a proof in ONE wavefront (the path the 4096-proof batches take) at this small batch.
     commit.rs:109-125 (oracle: O.commit)."""
     n, k, l = 1, 3, 1
-    ctx = make_ctx(N, n, k, l, env={"RZK_UPT": upt} if upt else {})
+    env = {"RZK_UPT": upt} if upt else {}
+    if io is not None:
+        env["RZK_UNIT_IO"] = io   # unit_io_kernel everywhere / nowhere (its third-prime pass and its two-prime rows)
+    ctx = make_ctx(N, n, k, l, env=env)
     P = P_of(ctx)
     rng = np.random.default_rng(700 + N)
     A = synth.key(rng, N, n, k, l)

@@ -26,6 +26,8 @@ KNOBS = [
     {"RZK_SLOT_SHARE_MIN": 0, "RZK_ROW_GROUPS": 0},
     {"RZK_BLOCK_MIN_LOGN": 10},
     {"RZK_PAIR_POLY": 0},   # N = 2048: one wavefront per polynomial (the round-2 kernels) instead of two
+    {"RZK_UNIT_IO": 1},     # key-product programs through unit_io_kernel at every N (default: N = 512 only)
+    {"RZK_UNIT_IO": 0},     # ... and through unit_kernel at N = 512
 ]
 
 

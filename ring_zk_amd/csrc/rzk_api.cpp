@@ -302,10 +302,10 @@ void key_row(rzk_ctx* c, PB& pb, int sign, uint32_t krow, uint8_t vop, uint32_t 
   }
 }
 
-// Challenge products as signed rotations (shift-add) instead of transforms: N = 512 and 1024.  At N = 2048 a
-// lane holds 32 outputs, the rotation kernels need > 200 VGPRs (one or two waves per SIMD) and measured slower
-// than the transform path.
-bool shift_ok(const rzk_ctx* c) { return c->use_shift && !c->small && c->logn <= 10; }
+// Challenge products as signed rotations (shift-add) instead of transforms.  At N = 2048 only with two wavefronts
+// per polynomial (16 outputs per thread): with one, a lane holds 32 outputs, the rotation kernels need > 200 VGPRs
+// (one or two waves per SIMD) and measured slower than the transform path (round 2).
+bool shift_ok(const rzk_ctx* c) { return c->use_shift && !c->small && (c->logn <= 10 || c->pair_poly); }
 
 int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
   const uint32_t n = c->n, k = c->k, l = c->l;
@@ -825,13 +825,13 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
     const bool pairs = c->logn == 11 && c->pair_poly;   // two wavefronts per polynomial
     const std::string tf = c->trusted ? "true" : "false";
     if (c->small) pi.kernel = "row_kernel_small";
-    else if (dp.shift) pi.kernel = "shift_row_kernel<" + L + ", " + tf + ">";
+    else if (dp.shift) pi.kernel = "shift_row_kernel<" + L + ", " + tf + (pairs ? ", PairTeam>" : ">");
     else if (dp.nblocks) pi.kernel = "row_block_kernel<" + L + (pairs ? ", BlockPairTeam>" : ">");
     else if (dp.ngroups) pi.kernel = "row_group_kernel<" + L + ", " + std::to_string(c->logn >= 11 ? 2 : RZK_GROUP_GM) + ">";
     else if (dp.d_slots) pi.kernel = "fwd_slots_kernel<" + L + "> + row_slots_kernel<" + L + ">";
     else if (dp.has_vec && c->vec_rows)
       pi.kernel = "row_kernel<" + L + ", " + (dp.has_shift ? "true" : "false") + (pairs ? ", PairTeam>" : ">");
-    else if (!dp.has_vec && c->unit_io)
+    else if (!dp.has_vec && c->unit_io && !(c->logn == 11 && dp.has_shift))
       pi.kernel = "unit_io_kernel<" + L + ", " + (dp.has_shift ? "true" : "false") + (pairs ? ", PairTeam>" : ">");
     else
       pi.kernel = "unit_kernel<" + L + ", " + (dp.has_vec ? "true" : "false") + ", " + (dp.has_shift ? "true" : "false") +

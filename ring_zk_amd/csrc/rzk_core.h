@@ -517,16 +517,22 @@ RZK_HD int64_t crt_finish(uint32_t stA, int np, const CrtConsts& C) {
 // Any multiplier is handled exactly (the cost grows with its number of non-zero coefficients).
 // Two register layouts: PAIR (coefficients g*128 + 2*lane + {0,1}: 16-byte global accesses, the stand-alone
 // kernel) and the phase-1 layout of the transforms (e*64 + lane: what the row kernel's epilogue uses).
-template <int LOGN, bool PAIR = true>
+template <int LOGN, bool PAIR = true, int LL = 6>
 struct ShiftGeo {
   static constexpr int N = 1 << LOGN;
-  static constexpr int E = N / 64;          // outputs per lane
-  static constexpr int G = E / 2;           // pairs per lane (PAIR layout)
-  static constexpr int WORDS = 2 * N;       // LDS words per wavefront
+  static constexpr int LANES = 1 << LL;     // threads of the team (one or two wavefronts)
+  static constexpr int E = N / LANES;       // outputs per thread
+  static constexpr int G = E / 2;           // pairs per thread (PAIR layout)
+  static constexpr int WORDS = 2 * N;       // LDS words per team
   RZK_HD static int lane_base(int lane) { return PAIR ? 2 * lane : lane; }
-  static constexpr int off(int i) { return PAIR ? (i >> 1) * 128 + (i & 1) : i * 64; }
+  static constexpr int off(int i) { return PAIR ? (i >> 1) * 2 * LANES + (i & 1) : i * LANES; }
   RZK_HD static int j(int lane, int i) { return lane_base(lane) + off(i); }   // coefficient of register i
 };
+// Teams of two wavefronts cannot walk the multiplier with ballot / readlane (each wavefront sees half of it): its
+// non-zero coefficients are compacted into a list {position, value} behind the image, kShiftListCap entries per
+// round (one round for a challenge; any multiplier is still handled exactly, in ceil(nonzeros / cap) rounds).
+constexpr int kShiftListCap = 256;
+constexpr int kShiftListWords = 2 * kShiftListCap + 4;   // entries, then the two wavefronts' counts
 
 // what of v goes into the image: the value itself, or one 16-bit half (two passes keep 64-bit sums exact
 // for multipliers of any size)
@@ -535,9 +541,9 @@ RZK_HD int32_t shift_part(int32_t v, int part) {
   return part == SHIFT_WHOLE ? v : (part == SHIFT_LOW16 ? (int32_t)((uint32_t)v & 0xffffu) : (v >> 16));
 }
 
-template <int LOGN, bool PAIR>
+template <int LOGN, bool PAIR, int LL = 6>
 RZK_HD void shift_fill(const int32_t* v, int lane, int32_t* ext, int part) {
-  using S = ShiftGeo<LOGN, PAIR>;
+  using S = ShiftGeo<LOGN, PAIR, LL>;
   int32_t* base = ext + S::lane_base(lane);
 #pragma unroll
   for (int i = 0; i < S::E; ++i) {
@@ -549,9 +555,9 @@ RZK_HD void shift_fill(const int32_t* v, int lane, int32_t* ext, int part) {
 
 // acc[i - I0] += coef * (X^s v)[j(lane, i)] for the registers I0 .. I0+IN-1 of one lane (T = int64_t: one
 // v_mad_i64_i32 per output).
-template <int LOGN, bool PAIR, typename T, int I0, int IN>
+template <int LOGN, bool PAIR, typename T, int I0, int IN, int LL = 6>
 RZK_HD void shift_accum(T* acc, int lane, int s, int32_t coef, const int32_t* ext) {
-  using S = ShiftGeo<LOGN, PAIR>;
+  using S = ShiftGeo<LOGN, PAIR, LL>;
   const int32_t* base = ext + (S::lane_base(lane) + S::N - s);
 #pragma unroll
   for (int i = 0; i < IN; ++i) acc[i] += (T)coef * (T)base[S::off(I0 + i)];

@@ -569,20 +569,20 @@ __device__ __forceinline__ void load_lift(uint32_t* x, const int64_t* __restrict
 // ---- challenge products as signed rotations (ShiftGeo, rzk_core.h): shared by shift_row_kernel and the
 // shift terms of row_kernel ---------------------------------------------------------------------------------
 
-template <int LOGN>
+template <int LOGN, int LL = 6>
 __device__ __forceinline__ void load_pairs(int32_t* v, const int64_t* __restrict__ src, int lane, uint32_t qhalf,
                                            uint32_t& bad, uint32_t& mx, bool trusted) {
-  using S = ShiftGeo<LOGN>;
+  using S = ShiftGeo<LOGN, true, LL>;
   const longlong2* __restrict__ p = reinterpret_cast<const longlong2*>(src);
   if (trusted) {
 #pragma unroll
     for (int g = 0; g < S::G; ++g) {
-      const longlong2 t = ld_stream(p + g * 64 + lane);
+      const longlong2 t = ld_stream(p + g * S::LANES + lane);
       v[2 * g] = (int32_t)t.x, v[2 * g + 1] = (int32_t)t.y;
     }
   } else {
 #pragma unroll
-    for (int g = 0; g < S::G; ++g) canon_pair(ld_stream(p + g * 64 + lane), qhalf, bad, mx, v[2 * g], v[2 * g + 1]);   // coefficients g*128 + 2*lane, +1
+    for (int g = 0; g < S::G; ++g) canon_pair(ld_stream(p + g * S::LANES + lane), qhalf, bad, mx, v[2 * g], v[2 * g + 1]);   // coefficients g*2*LANES + 2*lane, +1
   }
 }
 
@@ -614,24 +614,67 @@ __device__ __forceinline__ void shift_scan(int64_t* acc, const int32_t* a, int l
 // (Taking two non-zeros per trip, or sixteen outputs per scan, to keep more LDS reads in flight was measured
 // slower: the extra registers cost a wave per SIMD.)
 
+// ---- teams of two wavefronts: the multiplier's non-zeros as a list in LDS (kShiftListCap entries per round) ----
+// number of non-zero coefficients this WAVEFRONT holds
+template <int E>
+__device__ __forceinline__ uint32_t shift_count_nonzeros(const int32_t* a) {
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int i = 0; i < E; ++i) cnt += (uint32_t)__builtin_popcountll(__ballot(a[i] != 0));
+  return cnt;
+}
+// entries [r0, r0 + cap) of the team's list; `base` = entries of the wavefronts before this one
+template <int LOGN, bool PAIR, int LL>
+__device__ __forceinline__ void shift_list_write(const int32_t* a, int lane, uint32_t base, uint32_t r0, int32_t* list) {
+  using S = ShiftGeo<LOGN, PAIR, LL>;
+  uint32_t run = base - r0;   // (mod 2^32: entries before the window wrap to huge indices and are skipped)
+  int2* ent = reinterpret_cast<int2*>(list);
+#pragma unroll
+  for (int i = 0; i < S::E; ++i) {
+    const uint64_t m = __ballot(a[i] != 0);
+    const uint32_t idx = run + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+    if (a[i] != 0 && idx < (uint32_t)kShiftListCap) ent[idx] = make_int2(S::j(lane, i), a[i]);
+    run += (uint32_t)__builtin_popcountll(m);
+  }
+}
+// add the rotations of the list's first `nent` entries into IN outputs of every thread
+template <int LOGN, bool PAIR, int LL, int IN>
+__device__ __forceinline__ void shift_scan_list(int64_t* acc, const int32_t* list, uint32_t nent, int lane, const int32_t* ext) {
+  const int2* ent = reinterpret_cast<const int2*>(list);
+  const int l64 = lane & 63;
+#pragma unroll 1
+  for (uint32_t e0 = 0; e0 < nent; e0 += 64) {
+    const uint32_t m = nent - e0 < 64u ? nent - e0 : 64u;
+    const int2 mine = (uint32_t)l64 < m ? ent[e0 + l64] : make_int2(0, 0);   // 64 entries per trip, one per lane
+#pragma unroll 1
+    for (uint32_t e = 0; e < m; ++e) {
+      const int s = __builtin_amdgcn_readlane(mine.x, (int)e);
+      const int32_t coef = __builtin_amdgcn_readlane(mine.y, (int)e);
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      shift_accum<LOGN, PAIR, int64_t, 0, IN, LL>(acc, ln, s, coef, ext);
+    }
+  }
+}
+
 // Build the wave's 2N-word extended image of v (ShiftGeo, rzk_core.h) straight from global memory, in two rolled
 // halves so that only E/2 sixty-four-bit coefficients are in flight at a time.  measure: this is the first fill —
 // it also proves that v is canonical (canon_lo) and returns max |v| over the lane's coefficients.
-template <int LOGN, bool PAIR>
+template <int LOGN, bool PAIR, int LL = 6>
 __device__ __forceinline__ void shift_fill_from(const int64_t* __restrict__ pv, int lane, int32_t* ext, int part,
                                                 bool measure, bool canon, uint32_t qhalf, uint32_t& bad, uint32_t& mx,
                                                 uint32_t& maxabs) {
-  using S = ShiftGeo<LOGN, PAIR>;
-  constexpr int H = S::E / 2;               // registers per half; off(h*H + i) = off(i) + h * 32 * E in both layouts
-  constexpr int HOFF = 32 * S::E;
+  using S = ShiftGeo<LOGN, PAIR, LL>;
+  constexpr int H = S::E / 2;               // registers per half; off(h*H + i) = off(i) + h * H * LANES in both layouts
+  constexpr int HOFF = H * S::LANES;
 #pragma unroll 1
   for (int h = 0; h < 2; ++h) {
     int32_t vh[H];
     if (PAIR) {
-      const longlong2* __restrict__ p = reinterpret_cast<const longlong2*>(pv) + (size_t)h * (H / 2) * 64;
+      const longlong2* __restrict__ p = reinterpret_cast<const longlong2*>(pv) + (size_t)h * (H / 2) * S::LANES;
 #pragma unroll
       for (int g = 0; g < H / 2; ++g) {
-        const longlong2 t = ld_stream(p + g * 64 + lane);   // coefficients (h*H/2 + g)*128 + 2*lane, +1
+        const longlong2 t = ld_stream(p + g * S::LANES + lane);   // coefficients (h*H/2 + g)*2*LANES + 2*lane, +1
         if (canon) {
           canon_pair(t, qhalf, bad, mx, vh[2 * g], vh[2 * g + 1]);
         } else {
@@ -640,10 +683,10 @@ __device__ __forceinline__ void shift_fill_from(const int64_t* __restrict__ pv, 
         }
       }
     } else {
-      const int64_t* __restrict__ p = pv + (size_t)h * H * 64;
+      const int64_t* __restrict__ p = pv + (size_t)h * H * S::LANES;
 #pragma unroll
       for (int i = 0; i < H; ++i) {
-        const int64_t c = p[i * 64 + lane];
+        const int64_t c = p[i * S::LANES + lane];
         vh[i] = canon ? canon_lo_mx(c, qhalf, bad, mx) : (int32_t)c;
       }
     }
@@ -666,26 +709,31 @@ __device__ __forceinline__ void shift_fill_from(const int64_t* __restrict__ pv, 
 }
 
 // res[] (in [0,q)) +/-= (a (*) v) mod q for one product term; a[] holds the multiplier's low words in layout
-// PAIR, pv points at the other operand.  ext: the wave's 2N-word LDS image.  Wave-uniform control flow.
-// TO_MEM: res is a per-wave line in global memory indexed by coefficient (each lane touches only its own
-// coefficients) and `fresh` says that it holds nothing yet; otherwise res are the lane's E registers.
+// PAIR, pv points at the other operand.  ext: the team's 2N-word LDS image (teams of two: followed by the
+// kShiftListWords words of the non-zero list).  Team-uniform control flow.
+// TO_MEM: res is a per-team line in global memory indexed by coefficient (each thread touches only its own
+// coefficients) and `fresh` says that it holds nothing yet; otherwise res are the thread's E registers.
 // Sums are exact 64-bit integers (v_mad_i64_i32) as long as |a|_1 |v|_inf < 2^62; beyond that v goes in as
-// two 16-bit halves.  Eight of a lane's outputs are accumulated at a time (register budget).
+// two 16-bit halves.  Eight of a thread's outputs are accumulated at a time (register budget).
 // fault: set when v holds a non-canonical coefficient (the caller tests `a`).
-template <int LOGN, bool PAIR, bool TO_MEM>
+template <int LOGN, bool PAIR, bool TO_MEM, class TM = WaveTeam>
 __device__ __forceinline__ void shift_product(uint32_t* res, bool fresh, bool minus, const int32_t* a,
-                                              const int64_t* __restrict__ pv, int lane, int32_t* ext,
+                                              const int64_t* __restrict__ pv, int lane_in, int32_t* ext,
                                               const DevTables& T, bool& fault, bool trusted) {
-  using S = ShiftGeo<LOGN, PAIR>;
+  constexpr int LL = TM::LL;
+  int lane = lane_in;
+  if (LL != 6) asm volatile("" : "+v"(lane));   // per call: keeps the thread's 64-bit line / image addresses out of the kernel prologue
+  using S = ShiftGeo<LOGN, PAIR, LL>;
   constexpr int E = S::E;
   constexpr int HW = TO_MEM ? RZK_SHIFT_H_MEM : RZK_SHIFT_H;   // (the in-kernel rotation terms run with nothing else live)
   constexpr int H = HW < E ? HW : E;   // outputs per scan; chunk c covers registers c*H .. c*H+H-1
   constexpr int NCH = E / H;
+  constexpr bool LIST = LL != 6;
   const uint32_t q = T.crt.q, qhalf = T.crt.qhalf;
   // optimistic first fill with the whole values; it also measures v
   uint32_t vbad = 0, vmx = 0, maxv = 0;
-  wave_sync();   // earlier reads of the image are done before it is overwritten
-  shift_fill_from<LOGN, PAIR>(pv, lane, ext, SHIFT_WHOLE, true, !trusted, qhalf, vbad, vmx, maxv);
+  TM::sync();   // earlier reads of the image are done before it is overwritten
+  shift_fill_from<LOGN, PAIR, LL>(pv, lane, ext, SHIFT_WHOLE, true, !trusted, qhalf, vbad, vmx, maxv);
   if (!trusted) fault = fault || canon_fail(vbad, vmx, qhalf);
   uint64_t suma = 0;
 #pragma unroll
@@ -693,39 +741,66 @@ __device__ __forceinline__ void shift_product(uint32_t* res, bool fresh, bool mi
     const uint32_t ua = (uint32_t)a[i];
     suma += a[i] < 0 ? 0u - ua : ua;
   }
-  const double bound = (double)wave_sum_u56(suma) * (double)wave_max_u32(maxv);   // |exact product|_inf (E * 2^31 < 2^56 per lane)
+  const double bound = (double)TM::sum_u56(suma) * (double)TM::max_u32(maxv);   // |exact product|_inf (E * 2^31 < 2^56 per lane)
   const int npass = __builtin_amdgcn_readfirstlane(bound < 4.0e18 ? 1 : 2);        // 4.0e18 < 2^62
+  // teams of two: where this wavefront's non-zeros go in the list, and how many there are in all
+  int32_t* list = ext + S::WORDS;
+  uint32_t lbase = 0, ltotal = 1;   // (one wavefront: a single "round", the multiplier is walked in registers)
+  if (LIST) {
+    const uint32_t mine = shift_count_nonzeros<E>(a);
+    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane(lane >> 6);
+    if ((lane & 63) == 0) list[2 * kShiftListCap + w] = (int32_t)mine;
+    TM::sync();   // (also orders the image's fill before the first scan)
+    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane(list[2 * kShiftListCap]);
+    const uint32_t c1 = (uint32_t)__builtin_amdgcn_readfirstlane(list[2 * kShiftListCap + 1]);
+    lbase = w ? c0 : 0u;
+    ltotal = c0 + c1;
+  }
+  bool started = false;   // the TO_MEM line holds this product's partial sums
 #pragma unroll 1
   for (int pass = 0; pass < npass; ++pass) {
     if (npass == 2) {   // (never for a sparse +-1 challenge) the image is rebuilt from 16-bit halves
       uint32_t u0 = 0, u1 = 0, u2 = 0;
-      wave_sync();
-      shift_fill_from<LOGN, PAIR>(pv, lane, ext, pass == 0 ? SHIFT_LOW16 : SHIFT_HIGH16, false, false, qhalf, u0, u1, u2);
+      TM::sync();
+      shift_fill_from<LOGN, PAIR, LL>(pv, lane, ext, pass == 0 ? SHIFT_LOW16 : SHIFT_HIGH16, false, false, qhalf, u0, u1, u2);
     }
-    wave_sync();
+    if (!LIST || npass == 2) TM::sync();
 #pragma unroll 1
-    for (int ch = 0; ch < NCH; ++ch) {
-      int64_t acc[H];
+    for (uint32_t r0 = 0; r0 < (ltotal ? ltotal : 1u); r0 += LIST ? (uint32_t)kShiftListCap : 1u) {   // (a zero multiplier still initialises the sums)
+      uint32_t nent = 0;
+      if (LIST) {
+        if (r0 || pass) TM::sync();   // the previous round's scans are over
+        shift_list_write<LOGN, PAIR, LL>(a, lane, lbase, r0, list);
+        TM::sync();
+        nent = ltotal - r0 < (uint32_t)kShiftListCap ? ltotal - r0 : (uint32_t)kShiftListCap;   // (0 when there is no non-zero at all)
+      }
+#pragma unroll 1
+      for (int ch = 0; ch < NCH; ++ch) {
+        int64_t acc[H];
 #pragma unroll
-      for (int i = 0; i < H; ++i) acc[i] = 0;
-      shift_scan<LOGN, PAIR, H>(acc, a, lane, ext + ch * (64 * H));   // off(c*H + i) = off(i) + 64 H c in both layouts
+        for (int i = 0; i < H; ++i) acc[i] = 0;
+        // off(c*H + i) = off(i) + LANES H c in both layouts
+        if (LIST) shift_scan_list<LOGN, PAIR, LL, H>(acc, list, nent, lane, ext + ch * (S::LANES * H));
+        else shift_scan<LOGN, PAIR, H>(acc, a, lane, ext + ch * (S::LANES * H));
 #pragma unroll
-      for (int i = 0; i < H; ++i) {
-        uint32_t u = zq_from_i64(acc[i], T.crt);
-        if (pass) u = montq_u(u, T.crt.r48q, T.crt);   // high halves carry the weight 2^16
-        if (TO_MEM) {
-          uint32_t* slot = res + S::j(lane, i) + ch * (64 * H);
-          const uint32_t cur = (fresh && pass == 0) ? 0u : *slot;
-          *slot = minus ? subq(cur, u, q) : addq(cur, u, q);
-        } else {
+        for (int i = 0; i < H; ++i) {
+          uint32_t u = zq_from_i64(acc[i], T.crt);
+          if (pass) u = montq_u(u, T.crt.r48q, T.crt);   // high halves carry the weight 2^16
+          if (TO_MEM) {
+            uint32_t* slot = res + S::j(lane, i) + ch * (S::LANES * H);
+            const uint32_t cur = (fresh && !started) ? 0u : *slot;
+            *slot = minus ? subq(cur, u, q) : addq(cur, u, q);
+          } else {
 #pragma unroll
-          for (int c = 0; c < NCH; ++c) {   // register index c*H + i, selected without dynamic indexing
-            const uint32_t cur = res[c * H + i];
-            const uint32_t nw = minus ? subq(cur, u, q) : addq(cur, u, q);
-            res[c * H + i] = c == ch ? nw : cur;
+            for (int c = 0; c < NCH; ++c) {   // register index c*H + i, selected without dynamic indexing
+              const uint32_t cur = res[c * H + i];
+              const uint32_t nw = minus ? subq(cur, u, q) : addq(cur, u, q);
+              res[c * H + i] = c == ch ? nw : cur;
+            }
           }
         }
       }
+      started = true;
     }
   }
 }
@@ -1289,11 +1364,11 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
             for (int e = 0; e < E; ++e) a[e] = canon_lo_mx(pa[G::j_p1(lane, e)], qhalf, abad, amx);
             fault = fault || canon_fail(abad, amx, qhalf);
           }
-          shift_product<LOGN, false, true>(st_sh, t == 0, tm.sign < 0, a, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane,
+          shift_product<LOGN, false, true, TM>(st_sh, t == 0, tm.sign < 0, a, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane,
                                            reinterpret_cast<int32_t*>(lds), T, fault, trusted);
         }
         if (fault) input_fault(ops, flags, bo, lane);
-        wave_sync();   // the image is dead: slab and P may be overwritten
+        TM::sync();   // the image is dead: slab and P may be overwritten
         RZK_T1(t_rot);
       }
       int np = null_unit ? 1 : kMaxPrimes;
@@ -1596,11 +1671,11 @@ unit_io_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__
             for (int e = 0; e < E; ++e) a[e] = canon_lo_mx(pa[G::j_p1(lane, e)], qhalf, abad, amx);
             fault = fault || canon_fail(abad, amx, qhalf);
           }
-          shift_product<LOGN, false, true>(st_sh, t == 0, tm.sign < 0, a, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane,
+          shift_product<LOGN, false, true, TM>(st_sh, t == 0, tm.sign < 0, a, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane,
                                            reinterpret_cast<int32_t*>(lds), T, fault, trusted);
         }
         if (fault) input_fault(ops, flags, bo, lane);
-        wave_sync();   // the image is dead: slab and P may be overwritten
+        TM::sync();   // the image is dead: slab and P may be overwritten
       }
       if (nit == 0) {   // no products: additions / rotation terms only
         uint32_t u[E];
@@ -1855,11 +1930,11 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
           for (int e = 0; e < E; ++e) a[e] = canon_lo_mx(pa[G::j_p1(lane, e)], qhalf, abad, amx);
           fault = fault || canon_fail(abad, amx, qhalf);
         }
-        shift_product<LOGN, false, true>(st_sh, t == 0, tm.sign < 0, a, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane,
+        shift_product<LOGN, false, true, TM>(st_sh, t == 0, tm.sign < 0, a, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane,
                                          reinterpret_cast<int32_t*>(lds), T, fault, trusted);
       }
       if (fault) input_fault(ops, flags, bo, lane);
-      wave_sync();   // the image is dead: the slab and the state words may be overwritten
+      TM::sync();   // the image is dead: the slab and the state words may be overwritten
     }
     const bool has_terms = row.nterms > 0;
     int np = kMaxPrimes;
@@ -1898,29 +1973,33 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
 #ifndef RZK_SHIFT_MIN_WAVES
 #define RZK_SHIFT_MIN_WAVES 1
 #endif
-template <int LOGN>
-struct ShiftCfg {   // waves per workgroup: one wave's image is 8 * N bytes of LDS, 32 KiB per workgroup at most
-  static constexpr int WPB = 4;
+template <int LOGN, class TM = WaveTeam>
+struct ShiftCfg {   // teams per workgroup: one team's image is 8 * N bytes of LDS, 32 KiB per workgroup at most
+  static constexpr int TPB = TM::LL == 6 ? 4 : 1;
+  static constexpr int WORDS = ShiftGeo<LOGN, true, TM::LL>::WORDS + (TM::LL == 6 ? 0 : kShiftListWords);   // per team
 };
 
-template <int LOGN, bool TRUSTED>   // TRUSTED (Operands::trusted) is a template flag here: as a run-time branch around the loads
-                                    // it changed the compiler's load scheduling (79 instead of 116 VGPRs, 86 us instead of 77)
-__global__ void __launch_bounds__(64 * ShiftCfg<LOGN>::WPB, RZK_SHIFT_MIN_WAVES)
+template <int LOGN, bool TRUSTED, class TM = WaveTeam>   // TRUSTED (Operands::trusted) is a template flag here: as a run-time branch around the loads
+                                                         // it changed the compiler's load scheduling (79 instead of 116 VGPRs, 86 us instead of 77)
+__global__ void __launch_bounds__((ShiftCfg<LOGN, TM>::TPB << TM::LL), (TM::LL == 6 ? RZK_SHIFT_MIN_WAVES : 4))
 shift_row_kernel(const Program* __restrict__ prog, const Operands ops, const DevTables* __restrict__ Tp,
                  uint8_t* __restrict__ flags, const uint32_t ntasks) {
-  using S = ShiftGeo<LOGN>;
+  using S = ShiftGeo<LOGN, true, TM::LL>;
   constexpr int E = S::E;
   constexpr int N = S::N;
-  constexpr int WPB = ShiftCfg<LOGN>::WPB;
+  constexpr int LANES = S::LANES;
+  constexpr int TPB = ShiftCfg<LOGN, TM>::TPB;
   extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const int lane = threadIdx.x & 63;
-  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int32_t* slab = reinterpret_cast<int32_t*>(smem) + wave * S::WORDS;
+  const int lane = threadIdx.x & (LANES - 1);                                              // index inside the team
+  const uint32_t team = __builtin_amdgcn_readfirstlane(threadIdx.x >> TM::LL);
+  int32_t* slab = reinterpret_cast<int32_t*>(smem) + team * ShiftCfg<LOGN, TM>::WORDS;
   const DevTables& T = *Tp;
   const uint32_t q = T.crt.q;
   const uint32_t nrows = prog->nrows;
 
-  for (uint32_t task = blockIdx.x * WPB + wave; task < ntasks; task += gridDim.x * WPB) {
+  // (Tasks of several consecutive rows that keep their common multiplier — the challenge of z = y + r (.) d — in
+  // registers from row to row measured no gain at N = 512 / 1024 and a loss at N = 2048: the re-reads hit in L2.)
+  for (uint32_t task = blockIdx.x * TPB + team; task < ntasks; task += gridDim.x * TPB) {
     const uint32_t b = task / nrows;
     const uint32_t rowi = task - b * nrows;
     const uint32_t bo = ops.group > 1 ? b / ops.group : b;
@@ -1937,17 +2016,17 @@ shift_row_kernel(const Program* __restrict__ prog, const Operands ops, const Dev
         const Term tm = prog->terms[row.term0 + t];
         int32_t a[E];
         uint32_t abad = 0, amx = 0;
-        load_pairs<LOGN>(a, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), lane, qhalf, abad, amx, trusted);
+        load_pairs<LOGN, TM::LL>(a, operand_ptr(ops, tm.a_op, tm.a_off, b, bo, N), lane, qhalf, abad, amx, trusted);
         if (!trusted) fault = fault || canon_fail(abad, amx, qhalf);
-        shift_product<LOGN, true, false>(res, false, tm.sign < 0, a, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane,
-                                         slab, T, fault, trusted);
+        shift_product<LOGN, true, false, TM>(res, false, tm.sign < 0, a, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), lane,
+                                             slab, T, fault, trusted);
       }
-      // The sums move to the (now idle) image, each lane's pairs in its own 8-byte slots, so that the additions and
+      // The sums move to the (now idle) image, each thread's pairs in its own 8-byte slots, so that the additions and
       // the store can run as a rolled loop with few registers and four 16-byte loads in flight per addition.
-      wave_sync();
+      TM::sync();
       uint2* own = reinterpret_cast<uint2*>(slab) + lane;
 #pragma unroll
-      for (int g = 0; g < S::G; ++g) own[g * 64] = make_uint2(res[2 * g], res[2 * g + 1]);
+      for (int g = 0; g < S::G; ++g) own[g * LANES] = make_uint2(res[2 * g], res[2 * g + 1]);
     }
     constexpr int GC = S::G < 4 ? S::G : 4;   // pairs per trip
     uint32_t in_bad = 0, in_mx = 0;
@@ -1955,27 +2034,27 @@ shift_row_kernel(const Program* __restrict__ prog, const Operands ops, const Dev
 #pragma unroll 1
     for (int g0 = 0; g0 < S::G; g0 += GC) {
       uint32_t r[2 * GC];
-      const uint2* own = reinterpret_cast<const uint2*>(slab) + lane + g0 * 64;
+      const uint2* own = reinterpret_cast<const uint2*>(slab) + lane + g0 * LANES;
 #pragma unroll
       for (int g = 0; g < GC; ++g) {
-        const uint2 v = own[g * 64];
+        const uint2 v = own[g * LANES];
         r[2 * g] = v.x, r[2 * g + 1] = v.y;
       }
 #pragma unroll 1
       for (uint32_t ai = 0; ai < row.nadds; ++ai) {
         const AddTerm ad = prog->adds[row.add0 + ai];
         const longlong2* __restrict__ p =
-            reinterpret_cast<const longlong2*>(operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, N)) + g0 * 64 + lane;
+            reinterpret_cast<const longlong2*>(operand_ptr(ops, ad.op & ADD_OP_MASK, ad.off, b, bo, N)) + g0 * LANES + lane;
         int32_t av[2 * GC];
         if (trusted) {
 #pragma unroll
           for (int g = 0; g < GC; ++g) {
-            const longlong2 t = ld_stream(p + g * 64);
+            const longlong2 t = ld_stream(p + g * LANES);
             av[2 * g] = (int32_t)t.x, av[2 * g + 1] = (int32_t)t.y;
           }
         } else {
 #pragma unroll
-          for (int g = 0; g < GC; ++g) canon_pair(ld_stream(p + g * 64), qhalf, in_bad, in_mx, av[2 * g], av[2 * g + 1]);
+          for (int g = 0; g < GC; ++g) canon_pair(ld_stream(p + g * LANES), qhalf, in_bad, in_mx, av[2 * g], av[2 * g + 1]);
         }
         if (ad.sign >= 0) {
 #pragma unroll
@@ -1987,11 +2066,11 @@ shift_row_kernel(const Program* __restrict__ prog, const Operands ops, const Dev
       }
       if (row.mode == MODE_STORE) {
         int4* __restrict__ dst =
-            reinterpret_cast<int4*>(const_cast<int64_t*>(operand_ptr(ops, row.out_op, row.out_off, b, bo, N))) + g0 * 64 + lane;
+            reinterpret_cast<int4*>(const_cast<int64_t*>(operand_ptr(ops, row.out_op, row.out_off, b, bo, N))) + g0 * LANES + lane;
 #pragma unroll
         for (int g = 0; g < GC; ++g) {
           const int64_t c0 = center_from_zq(r[2 * g], T.crt), c1 = center_from_zq(r[2 * g + 1], T.crt);
-          st_stream(dst + g * 64, make_int4((int32_t)c0, (int32_t)(c0 >> 32), (int32_t)c1, (int32_t)(c1 >> 32)));
+          st_stream(dst + g * LANES, make_int4((int32_t)c0, (int32_t)(c0 >> 32), (int32_t)c1, (int32_t)(c1 >> 32)));
         }
       } else {
 #pragma unroll
@@ -2000,9 +2079,9 @@ shift_row_kernel(const Program* __restrict__ prog, const Operands ops, const Dev
     }
     if (fault || canon_fail(in_bad, in_mx, qhalf)) input_fault(ops, flags, bo, lane);
     if (row.mode != MODE_STORE) {
-      if (__any(nz) && lane == 0) flags[bo] = 0;
+      if (__any(nz) && (lane & 63) == 0) flags[bo] = 0;
     }
-    wave_sync();   // the next task's image overwrites the slots read above
+    TM::sync();   // the next task's image overwrites the slots read above
   }
 }
 
@@ -2915,6 +2994,17 @@ static inline unsigned grid_for(uint64_t tasks, int num_cus, int waves_per_block
 
 size_t row_scratch_words(int logn, int num_cus) { return (size_t)num_cus * 8 * 4 * (((size_t)kScratchLines << logn) + 16); }
 
+// LDS words of one team in unit_kernel / row_kernel: transposition slab + one N-word buffer; a rotation term's image
+// (2N words) fits inside that, the non-zero list of a two-wavefront team comes on top
+template <int LOGN, class TM, bool HAS_SHIFT>
+constexpr size_t team_lds_words() {
+  using G = Geo<LOGN, TM::LL>;
+  constexpr size_t base = G::LDS_WORDS + G::N;
+  constexpr size_t rot = (HAS_SHIFT && TM::LL != 6) ? 2 * (size_t)G::N + kShiftListWords : 0;
+  static_assert(!(HAS_SHIFT && TM::LL != 6) || TM::kTeamsPerBlock == 1, "the list lies behind the team's own buffers");
+  return (((base > rot ? base : rot) + 3) / 4) * 4;
+}
+
 template <int LOGN, bool HAS_VEC, bool HAS_SHIFT, class TM = WaveTeam>
 static int launch_units_t(const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, const Operands& ops,
                           const uint32_t* d_key_ntt, const double* d_key_l2, const DevTables* T, const uint32_t* d_tw,
@@ -2922,7 +3012,7 @@ static int launch_units_t(const LaunchCfg& cfg, const Program* d_prog, const Wav
   using G = Geo<LOGN, TM::LL>;
   constexpr int TPB = TM::kTeamsPerBlock;
   // per team: transposition slab + P
-  const size_t lds = TPB * (size_t)(G::LDS_WORDS + G::N) * sizeof(uint32_t);
+  const size_t lds = TPB * team_lds_words<LOGN, TM, HAS_SHIFT>() * sizeof(uint32_t);
   if (lds > 48 * 1024) {   // large dynamic LDS needs an opt-in; per device, so set before every launch (cheap, idempotent)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&unit_kernel<LOGN, HAS_VEC, HAS_SHIFT, TM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2961,7 +3051,7 @@ static int launch_rows_t(const LaunchCfg& cfg, const Program* d_prog, const Oper
                          uint8_t* d_flags, uint32_t ntasks) {
   using G = Geo<LOGN, TM::LL>;
   constexpr int TPB = TM::kTeamsPerBlock;
-  const size_t lds = TPB * (size_t)(G::LDS_WORDS + G::N) * sizeof(uint32_t);   // per team: transposition slab + state word A
+  const size_t lds = TPB * team_lds_words<LOGN, TM, HAS_SHIFT>() * sizeof(uint32_t);   // per team: transposition slab + state word A
   if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&row_kernel<LOGN, HAS_SHIFT, TM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2984,8 +3074,8 @@ int launch_rows(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t 
   switch (logn) {
     case 9: return has_shift ? launch_rows_t<9, true>(RZK_ROWS_ARGS) : launch_rows_t<9, false>(RZK_ROWS_ARGS);
     case 10: return has_shift ? launch_rows_t<10, true>(RZK_ROWS_ARGS) : launch_rows_t<10, false>(RZK_ROWS_ARGS);
-    case 11:   // rotation terms are not built for N = 2048 (rzk_api.cpp, shift_ok)
-      if (has_shift) return -1;
+    case 11:   // rotation terms at N = 2048: teams of two only (rzk_api.cpp, shift_ok)
+      if (has_shift) return cfg.pair_poly ? launch_rows_t<11, true, PairTeam>(RZK_ROWS_ARGS) : -1;
       return cfg.pair_poly ? launch_rows_t<11, false, PairTeam>(RZK_ROWS_ARGS) : launch_rows_t<11, false>(RZK_ROWS_ARGS);
   }
 #undef RZK_ROWS_ARGS
@@ -3003,7 +3093,7 @@ int launch_units(int logn, const LaunchCfg& cfg, const Program* d_prog, const Wa
   const uint32_t ntasks = (uint32_t)(batch * tpe);
   const uint32_t wpt = (work_per_entry + tpe - 1) / tpe;   // transforms per task (estimate, for the progress priorities)
 #define RZK_UNIT_ARGS cfg, d_prog, d_wp, ops, d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks, units_per_task, tpe, wpt
-  if (!has_vec && cfg.unit_io) {   // key-product programs: every operand read once (unit_io_kernel)
+  if (!has_vec && cfg.unit_io && !(logn == 11 && has_shift)) {   // key-product programs: every operand read once (unit_io_kernel)
     switch (logn) {
       case 9: return has_shift ? launch_units_io_t<9, true>(RZK_UNIT_ARGS) : launch_units_io_t<9, false>(RZK_UNIT_ARGS);
       case 10: return has_shift ? launch_units_io_t<10, true>(RZK_UNIT_ARGS) : launch_units_io_t<10, false>(RZK_UNIT_ARGS);
@@ -3021,8 +3111,11 @@ int launch_units(int logn, const LaunchCfg& cfg, const Program* d_prog, const Wa
   switch (logn) {
     RZK_UNIT_CASE(9)
     RZK_UNIT_CASE(10)
-    case 11:   // rotation terms are not built for N = 2048 (rzk_api.cpp, shift_ok)
-      if (has_shift) return -1;
+    case 11:   // rotation terms at N = 2048: teams of two only (rzk_api.cpp, shift_ok)
+      if (has_shift) {
+        if (!cfg.pair_poly) return -1;
+        return has_vec ? launch_units_t<11, true, true, PairTeam>(RZK_UNIT_ARGS) : launch_units_t<11, false, true, PairTeam>(RZK_UNIT_ARGS);
+      }
       if (cfg.pair_poly)
         return has_vec ? launch_units_t<11, true, false, PairTeam>(RZK_UNIT_ARGS) : launch_units_t<11, false, false, PairTeam>(RZK_UNIT_ARGS);
       return has_vec ? launch_units_t<11, true, false>(RZK_UNIT_ARGS) : launch_units_t<11, false, false>(RZK_UNIT_ARGS);
@@ -3032,22 +3125,29 @@ int launch_units(int logn, const LaunchCfg& cfg, const Program* d_prog, const Wa
   return -1;
 }
 
-template <int LOGN>
+template <int LOGN, class TM = WaveTeam>
 static int launch_shift_t(const LaunchCfg& cfg, const Program* d_prog, const Operands& ops, const DevTables* T,
                           uint8_t* d_flags, uint32_t ntasks) {
-  using S = ShiftGeo<LOGN>;
-  constexpr int WPB = ShiftCfg<LOGN>::WPB;
-  // One wave's image is 8 N bytes.  The workgroup asks for at least 40 KiB so that a CU holds four workgroups = 4 waves per
+  constexpr int TPB = ShiftCfg<LOGN, TM>::TPB;
+  // One team's image is 8 N bytes.  The workgroup asks for at least 40 KiB so that a CU holds four workgroups = 4 waves per
   // SIMD: with the 79 VGPRs the kernel needs, five or six would fit, and measured slower (response rows at N = 1024:
   // 86.7 us against 77.5 us at four — the kernel is co-bound by the LDS pipe, more waves only add contention).
-  size_t lds = (size_t)WPB * S::WORDS * sizeof(uint32_t);
-  if (LOGN >= 10 && lds < 40 * 1024) lds = 40 * 1024;   // (N = 512 keeps its 6 waves per SIMD: 4-KiB images, measured fine in round 2)
-  const unsigned grid = grid_for(ntasks, cfg.num_cus, WPB, 16);
+  // Teams of two (N = 2048): 18 KiB per 128-thread workgroup, eight workgroups = 4 waves per SIMD.
+  size_t lds = (size_t)TPB * ShiftCfg<LOGN, TM>::WORDS * sizeof(uint32_t);
+  if (TM::LL == 6 && LOGN >= 10 && lds < 40 * 1024) lds = 40 * 1024;   // (N = 512 keeps its 6 waves per SIMD: 4-KiB images, measured fine in round 2)
+  if (lds > 48 * 1024) {
+    hipError_t e = ops.trusted ? hipFuncSetAttribute(reinterpret_cast<const void*>(&shift_row_kernel<LOGN, true, TM>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                               : hipFuncSetAttribute(reinterpret_cast<const void*>(&shift_row_kernel<LOGN, false, TM>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const unsigned grid = grid_for(ntasks, cfg.num_cus, TPB, TM::LL == 6 ? 16 : 64);
   if (ops.trusted)
-    hipLaunchKernelGGL((shift_row_kernel<LOGN, true>), dim3(grid), dim3(64 * WPB), lds, (hipStream_t)cfg.stream, d_prog, ops,
+    hipLaunchKernelGGL((shift_row_kernel<LOGN, true, TM>), dim3(grid), dim3(TPB << TM::LL), lds, (hipStream_t)cfg.stream, d_prog, ops,
                        T, d_flags, ntasks);
   else
-    hipLaunchKernelGGL((shift_row_kernel<LOGN, false>), dim3(grid), dim3(64 * WPB), lds, (hipStream_t)cfg.stream, d_prog, ops,
+    hipLaunchKernelGGL((shift_row_kernel<LOGN, false, TM>), dim3(grid), dim3(TPB << TM::LL), lds, (hipStream_t)cfg.stream, d_prog, ops,
                        T, d_flags, ntasks);
   RZK_LAUNCH_CHECK();
   return 0;
@@ -3061,6 +3161,7 @@ int launch_shift_rows(int logn, const LaunchCfg& cfg, const Program* d_prog, uin
   switch (logn) {
     case 9: return launch_shift_t<9>(cfg, d_prog, ops, T, d_flags, ntasks);
     case 10: return launch_shift_t<10>(cfg, d_prog, ops, T, d_flags, ntasks);
+    case 11: return cfg.pair_poly ? launch_shift_t<11, PairTeam>(cfg, d_prog, ops, T, d_flags, ntasks) : -1;   // (rzk_api.cpp, shift_ok)
   }
   return -1;
 }

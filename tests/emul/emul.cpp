@@ -129,26 +129,27 @@ int polymul(int np, uint64_t q, const int64_t* a, const int64_t* b, int64_t* out
 
 // out = d * v in Z_q[X]/(X^N+1), centred, by the shift-add scheme of the challenge products (ShiftGeo):
 // passes = 1: whole values, 2: two 16-bit halves; outputs accumulated half a lane at a time as in the kernels.
-template <int LOGN, bool PAIR>
+template <int LOGN, bool PAIR, int LL = 6>
 int shift_product(int passes, uint64_t q, const int64_t* d, const int64_t* v, int64_t* out) {
-  using S = ShiftGeo<LOGN, PAIR>;
+  using S = ShiftGeo<LOGN, PAIR, LL>;
   constexpr int H = S::E / 2;
+  constexpr int LANES = S::LANES;
   CrtConsts C;
   if (!host::make_crt_consts(q, C)) return -1;
   static int32_t ext[S::WORDS];
-  static int32_t vr[64][S::E];
-  static uint32_t tr[64][S::E];
-  for (int l = 0; l < 64; ++l)
+  static int32_t vr[LANES][S::E];
+  static uint32_t tr[LANES][S::E];
+  for (int l = 0; l < LANES; ++l)
     for (int i = 0; i < S::E; ++i) vr[l][i] = (int32_t)v[S::j(l, i)];
   for (int pass = 0; pass < passes; ++pass) {
     const int part = passes == 2 ? (pass == 0 ? SHIFT_LOW16 : SHIFT_HIGH16) : SHIFT_WHOLE;
-    for (int l = 0; l < 64; ++l) shift_fill<LOGN, PAIR>(vr[l], l, ext, part);
-    for (int l = 0; l < 64; ++l)
+    for (int l = 0; l < LANES; ++l) shift_fill<LOGN, PAIR, LL>(vr[l], l, ext, part);
+    for (int l = 0; l < LANES; ++l)
       for (int half = 0; half < 2; ++half) {
         int64_t acc[H] = {0};
         for (int s = 0; s < S::N; ++s) {
           const int32_t coef = (int32_t)d[s];
-          if (coef != 0) shift_accum<LOGN, PAIR, int64_t, 0, H>(acc, l, s, coef, ext + half * (S::N / 2));
+          if (coef != 0) shift_accum<LOGN, PAIR, int64_t, 0, H, LL>(acc, l, s, coef, ext + half * (S::N / 2));
         }
         for (int i = 0; i < H; ++i) {
           const uint32_t u = zq_from_i64(acc[i], C);
@@ -157,7 +158,7 @@ int shift_product(int passes, uint64_t q, const int64_t* d, const int64_t* v, in
         }
       }
   }
-  for (int l = 0; l < 64; ++l)
+  for (int l = 0; l < LANES; ++l)
     for (int i = 0; i < S::E; ++i) out[S::j(l, i)] = center_from_zq(tr[l][i], C);
   return 0;
 }
@@ -166,6 +167,8 @@ int shift_product(int passes, uint64_t q, const int64_t* d, const int64_t* v, in
 
 extern "C" {
 int emul_shift_product(int logn, int pair, int passes, uint64_t q, const int64_t* d, const int64_t* v, int64_t* out) {
+  if (logn == 1011)   // N = 2048, two-wavefront team
+    return pair ? shift_product<11, true, 7>(passes, q, d, v, out) : shift_product<11, false, 7>(passes, q, d, v, out);
   switch (logn) {
     case 9: return pair ? shift_product<9, true>(passes, q, d, v, out) : shift_product<9, false>(passes, q, d, v, out);
     case 10: return pair ? shift_product<10, true>(passes, q, d, v, out) : shift_product<10, false>(passes, q, d, v, out);

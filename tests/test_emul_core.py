@@ -139,10 +139,11 @@ def test_emulated_polymul_fewer_primes(emul, logn):
 
 
 @pytest.mark.parametrize("pair", [1, 0])
-@pytest.mark.parametrize("logn", [9, 10, 11])
+@pytest.mark.parametrize("logn", [9, 10, 11, 1011])
 def test_emulated_shift_product(emul, logn, pair):
-    """Challenge products as signed negacyclic rotations (ShiftGeo in rzk_core.h), one and two passes."""
-    N = 1 << logn
+    """Challenge products as signed negacyclic rotations (ShiftGeo in rzk_core.h), one and two passes
+    (1011: N = 2048 in the layout of a two-wavefront team)."""
+    N = 1 << (logn % 1000)
     rng = np.random.default_rng(500 + logn)
 
     def run(passes, d, v):

@@ -231,6 +231,11 @@ def test_config5_shape_vs_oracle(torch_mod):
     dict(N=2048, shape=(2, 5, 2), V=2, env={"RZK_UNIT_IO": 1, "RZK_BLOCK_MIN_LOGN": 12}),
     dict(N=512, shape=(2, 5, 2), V=2, env={"RZK_UNIT_IO": 0, "RZK_ROW_GROUPS": 0}),
     dict(N=512, shape=(2, 5, 2), V=2, env={"RZK_ROW_GROUPS": 0}),
+    # N = 2048, two wavefronts per polynomial: challenge products by transforms (the default takes rotations with the
+    # non-zero list in LDS: shift_row_kernel<11, ., PairTeam> and the HAS_SHIFT variants of unit_kernel / row_kernel)
+    dict(N=2048, shape=(1, 3, 1), V=2, env={"RZK_SHIFT": 0}),
+    dict(N=2048, shape=(2, 5, 2), V=2, env={"RZK_SHIFT": 0}),
+    dict(N=2048, shape=(2, 5, 2), V=2, env={"RZK_VEC_ROWS": 0, "RZK_BLOCK_MIN_LOGN": 12}),   # unit_kernel<11, true, true, PairTeam>
 ])
 def test_forced_kernel_paths_vs_oracle(torch_mod, cfg):
     N, (n, k, l), V = cfg["N"], cfg["shape"], cfg["V"]
@@ -301,7 +306,8 @@ def _open_proof(ctx, B, seed):
     dict(N=512),                               # fused norm predicate + rotation term (the fast path)
     dict(N=1024, env={"RZK_SHIFT": 0}),        # challenge product by transforms
     dict(N=512, b=64),                         # verify bound >= 2^24: separate exact norm kernel
-    dict(N=2048),                              # no rotations at this size
+    dict(N=2048),                              # rotation term walked from the non-zero list of a two-wavefront team
+    dict(N=2048, env={"RZK_PAIR_POLY": 0}),    # one wavefront per polynomial: no rotations at this size
     dict(N=16, kappa=8),                       # schoolbook kernel (the reference's test size, tests/test.rs:8)
     dict(N=1024, shape=(2, 5, 2)),             # two-step A1 relation: grouped a1.z + rotation rows
 ])

@@ -458,7 +458,9 @@ def main():
     elapsed = time.perf_counter() - t0
 
     accepted, ok_cnt = int(acc_s.item()), int(ok_s.item())
-    assert accepted == B and ok_cnt == B, f"rank {rank}: {accepted}/{B} accepted, {ok_cnt}/{B} commit-ok"
+    # (RZK_BENCH_DIAG=1: timing-only runs of the diagnostic library builds of DESIGN.md §6, whose results are wrong on purpose)
+    diag = os.environ.get("RZK_BENCH_DIAG", "0") == "1"
+    assert diag or (accepted == B and ok_cnt == B), f"rank {rank}: {accepted}/{B} accepted, {ok_cnt}/{B} commit-ok"
 
     elapsed, tot_acc, per_rank = shard.reduce_result(dist, elapsed, accepted, red_dev, gather=True)
     proofs = B * world * args.steps
@@ -632,7 +634,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32",
-            "data": "synthetic",
+            "data": "synthetic" if not diag else "synthetic; DIAGNOSTIC run (RZK_BENCH_DIAG=1): results not checked, not a measurement of the product",
             "config": {
                 "workload": f"{args.workload.capitalize()}Proof cycle, N={N}, (n,k,l)=({n},{k},{l}), kappa=36, "
                             + (f"V={V} summands, " if args.workload == "sum" else "") + f"batch={B} proofs per GPU"

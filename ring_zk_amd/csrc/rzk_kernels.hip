@@ -1398,7 +1398,13 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
             const bool chk = first && (im.flags & (TERM_CHECK | TERM_CHECK2));
             {
               RZK_T0();
-              load_lift<LOGN, TM>(x, operand_ptr(ops, im.b_op, im.b_off, b, bo, N), ln, pc, first, nb, chk, ops.norm_limit, below, qhalf,
+#ifdef RZK_EXPERIMENT_REREAD   // diagnostic builds only (wrong results): what the launch would cost if the operand reads
+                               // after the first prime's came from L2 — 1: units of two rows only, 2: every unit
+              const uint32_t b_ld = (!first && (RZK_EXPERIMENT_REREAD >= 2 || pair)) ? (b & 63u) : b;
+#else
+              const uint32_t b_ld = b;
+#endif
+              load_lift<LOGN, TM>(x, operand_ptr(ops, im.b_op, im.b_off, b_ld, bo, N), ln, pc, first, nb, chk, ops.norm_limit, below, qhalf,
                               trusted, fault);
               RZK_T1(t_load);
             }

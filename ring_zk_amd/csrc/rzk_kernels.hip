@@ -393,7 +393,11 @@ __device__ __forceinline__ const int64_t* operand_ptr(const Operands& ops, uint3
                                                        uint32_t b, uint32_t bo, int n_coef) {
   uint32_t idx = ops.outer[op] ? bo : b;
 #ifdef RZK_EXPERIMENT_ALIAS   // diagnostic builds only: every batch entry uses the data of entry (index mod 64), so
-  idx &= (uint32_t)(RZK_EXPERIMENT_ALIAS - 1);   // (a power of two: 64 keeps operands and results in L2, 1024 in the Infinity Cache) — what the launch would cost without its HBM traffic
+#ifndef RZK_EXPERIMENT_ALIAS_OPS
+#define RZK_EXPERIMENT_ALIAS_OPS 0xffffffffu   // bit i: operand i of the row program is aliased (e.g. Open commit: 7 = x, r, y read; 24 = c, t written)
+#endif
+  if ((RZK_EXPERIMENT_ALIAS_OPS >> op) & 1u)
+    idx &= (uint32_t)(RZK_EXPERIMENT_ALIAS - 1);   // (a power of two: 64 keeps operands and results in L2, 1024 in the Infinity Cache) — what the launch would cost without its HBM traffic
 #endif
   return ops.base[op] + ((uint64_t)idx * ops.stride[op] + off) * (uint64_t)n_coef;
 }
@@ -1313,6 +1317,9 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
   const uint32_t nunits = wp->nunits;
 
   // progress of this wave through its share of the launch, in transforms (work_per_task: the host's estimate)
+#ifndef RZK_TOUCH_NEXT
+#define RZK_TOUCH_NEXT 0   // experiment: L2 touch of the next item's operand ahead of the current transform
+#endif
 #ifndef RZK_UNIT_ROT
 #define RZK_UNIT_ROT 0   // (rotating the unit order per workgroup measured no gain)
 #endif
@@ -1422,6 +1429,17 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
                 kreg[4 * g] = kv.x, kreg[4 * g + 1] = kv.y, kreg[4 * g + 2] = kv.z, kreg[4 * g + 3] = kv.w;
               }
             }
+#if RZK_TOUCH_NEXT
+            // one dword per 128-byte line of the NEXT item's operand, requested behind the key entry (the memory counter
+            // is in order: the key can be consumed while this is still in flight) and consumed after the product below:
+            // the line fetches from HBM then overlap this item's transform
+            uint32_t touch = 0;
+            if (first && !last) {
+              const Item nx = table_load(&wp->items[un.item0 + it + 1]);
+              const uint32_t* __restrict__ tp = reinterpret_cast<const uint32_t*>(operand_ptr(ops, nx.b_op, nx.b_off, b, bo, N));
+              touch = tp[(size_t)(ln & (N / 16 - 1)) * 32];
+            }
+#endif
             {
               RZK_T0();
               wave_fwd<LOGN, TM>(x, ln, lds, twf, pc);
@@ -1454,6 +1472,9 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
               if (vec) mac_park<LOGN, false, TM>(x, xb, im.signA < 0, P4, ln, it == 0, pc);
               else if (feedsA) mac_park<LOGN, false, TM>(x, kreg, im.signA < 0, P4, ln, it == 0, pc);
               RZK_T1(t_mac);
+#if RZK_TOUCH_NEXT
+              asm volatile("" ::"v"(touch));
+#endif
               continue;
             }
             RZK_T0();

@@ -108,6 +108,7 @@ struct rzk_ctx {
   bool use_pairs = true;               // unit_kernel: pair rows that share their last operand (RZK_PAIRS=0 turns it off, tuning)
   int group_max = 1;                   // rows per group of row_group_kernel (group_max_for; RZK_GROUP_MAX overrides, tuning)
   bool use_shift = true;               // challenge products as signed rotations (shift_row_kernel) instead of transforms
+  bool preset_in_kernel = true;        // verdict flags initialised by the unit kernels themselves where one team owns an entry (RZK_PRESET_IN_KERNEL=0: always a fill launch)
   bool small = false;                  // N < 512: schoolbook kernels (rzk_kernels.hip, "small ring degrees")
   uint32_t r2q = 0;                    // 2^64 mod q
   uint32_t* d_key_mont = nullptr;      // small N: key entries as Montgomery-form residues mod q
@@ -790,12 +791,28 @@ struct OpSpec {
 // `group` > 1: the batch is B*group (proof, summand) pairs; operands with outer != 0 and the flags are per proof
 // sticky: a non-canonical input coefficient fails the CALL (prover-side / Mat-level entry points); verifier-side
 // programs pass false — there the offending proof's verdict flag is cleared and the call succeeds.
+int check_launch(rzk_ctx* c, int lrc, const char* what);
+
+// preset_value != 0: every verdict flag (nflags of them) starts at that value — written by the launch itself when one
+// team evaluates all rows of a batch entry (no 5-us fill launch in front of a 75-us kernel), by a fill launch otherwise.
 int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& specs, uint8_t* flags,
-                uint32_t group, uint64_t batch, uint64_t norm_limit = 0, bool sticky = true) {
+                uint32_t group, uint64_t batch, uint64_t norm_limit = 0, bool sticky = true, uint8_t preset_value = 0,
+                uint64_t nflags = 0) {
   DevProg dp;
   int rc = get_program(c, id, var, dp);
   if (rc != RZK_OK) return rc;
   if (specs.size() > (size_t)kMaxOperands) return fail(c, RZK_E_ARG, "too many operands");
+  // units of one batch entry per task: all of them (one team per entry: equal-cost tasks, no tail) once the batch alone
+  // fills the chip's wave slots; one unit per task below that
+  uint32_t upt = batch >= (uint64_t)c->num_cus * 16 ? dp.nunits : 1;
+  if (c->units_per_task) upt = c->units_per_task;   // RZK_UPT (tuning)
+  const bool unit_path = !c->small && !dp.shift && !dp.nblocks && !dp.ngroups && !dp.d_slots && !(dp.has_vec && c->vec_rows);
+  const bool preset_in_kernel = preset_value && flags && c->preset_in_kernel && unit_path && upt >= dp.nunits && dp.nunits > 0 &&
+                                (group ? group : 1) == 1 && nflags == batch;
+  if (preset_value && flags && !preset_in_kernel) {
+    rc = check_launch(c, launch_fill_u8(cfg_of(c), flags, preset_value, nflags), "flag preset");
+    if (rc != RZK_OK) return rc;
+  }
   Operands ops{};
   for (size_t i = 0; i < specs.size(); ++i) {
     ops.base[i] = const_cast<int64_t*>(specs[i].base);
@@ -807,6 +824,7 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
   ops.norm_limit = norm_limit;
   ops.bad = sticky ? c->d_bad : nullptr;
   ops.trusted = c->trusted ? 1u : 0u;
+  ops.preset = preset_in_kernel ? preset_value : 0u;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->prof) {
     if (c->prof_used == c->prof_events.size()) {
@@ -884,10 +902,6 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
                                      flags ? flags + b0 / grp : nullptr, nb, dp.np_store);
     }
   } else {
-    // one wavefront per batch entry (all units back to back: equal-cost tasks, no tail) once the batch alone fills
-    // the chip's wave slots; one unit per task below that
-    uint32_t upt = batch >= (uint64_t)c->num_cus * 16 ? dp.nunits : 1;
-    if (c->units_per_task) upt = c->units_per_task;   // RZK_UPT (tuning)
     if (dp.has_vec && c->vec_rows) {
       lrc = launch_rows((int)c->logn, cfg_of(c), dp.d, dp.nrows, dp.has_shift, ops, c->d_key_ntt, c->d_key_l2, c->dT, c->d_tw,
                         c->d_row_scratch, flags, batch);
@@ -937,11 +951,7 @@ int run_program_checked(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSp
   // two-bit verdicts are cleared with word atomics: the flag array must be made of whole aligned words
   if (dp.two_bit && ((reinterpret_cast<uintptr_t>(flags) & 3u) || (nflags & 3u))) return RZK_E_UNSUPPORTED;
   const uint8_t all_ok = dp.two_bit ? 3 : 1;
-  if (preset) {
-    rc = check_launch(c, launch_fill_u8(cfg_of(c), flags, all_ok, nflags), "flag preset");
-    if (rc != RZK_OK) return rc;
-  }
-  return run_program(c, id, var | 1, specs, flags, group, batch, lim, sticky);
+  return run_program(c, id, var | 1, specs, flags, group, batch, lim, sticky, preset ? all_ok : (uint8_t)0, nflags);
 }
 
 bool can_fuse(rzk_ctx* c, int id, uint32_t var, uint64_t bound) {
@@ -1066,6 +1076,7 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
     if (g >= 1 && g <= (c->logn >= 11 ? 2 : RZK_GROUP_GM)) c->group_max = g;   // bounded by the compiled accumulators
   }
   if (const char* e = std::getenv("RZK_SHIFT")) c->use_shift = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RZK_PRESET_IN_KERNEL")) c->preset_in_kernel = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_PAIRS")) c->use_pairs = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_UPT")) c->units_per_task = (uint32_t)std::atoi(e);
   if (const char* e = std::getenv("RZK_VEC_ROWS")) c->vec_rows = std::atoi(e) != 0;

@@ -176,7 +176,10 @@ struct Operands {
   // device, or validated before): the canonical test is skipped (rzk_ctx_trust_device_outputs).  Norm predicates and
   // the norm measurements that fix the prime count are evaluated as always.
   uint32_t trusted;
-  uint32_t pad2;
+  // != 0: the launch itself initialises every verdict flag to this value before its rows can clear it — only set when
+  // one team evaluates ALL rows of a batch entry and flags are per entry (unit kernels with units_per_task = all, group 1);
+  // otherwise the host presets the flags with a fill launch of its own (rzk_api.cpp, run_program)
+  uint32_t preset;
 };
 
 // ---- launchers (defined in rzk_kernels.hip) --------------------------------------------------------------------

@@ -1339,6 +1339,10 @@ unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp
     const uint32_t u0 = (task - b * tasks_per_entry) * units_per_task;
     const uint32_t u1 = u0 + units_per_task < nunits ? u0 + units_per_task : nunits;
     const uint32_t bo = ops.group > 1 ? b / ops.group : b;
+    if (ops.preset) {   // this team evaluates every row of the entry (host: one task per entry, one flag per entry): it owns the flag
+      if (lane == 0) flags[bo] = (uint8_t)ops.preset;
+      if (TM::LL != 6) TM::sync();   // the other wavefront of a pair may clear it
+    }
     const uint32_t unit_rot = (u1 - u0) > 1 ? rot_sel % (u1 - u0) : 0u;
 #pragma unroll 1
     for (uint32_t uk = u0; uk < u1; ++uk) {
@@ -1674,6 +1678,10 @@ unit_io_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__
     const uint32_t u0 = (task - b * tasks_per_entry) * units_per_task;
     const uint32_t u1 = u0 + units_per_task < nunits ? u0 + units_per_task : nunits;
     const uint32_t bo = ops.group > 1 ? b / ops.group : b;
+    if (ops.preset) {   // as in unit_kernel: the team that evaluates the whole entry initialises its flag
+      if (lane == 0) flags[bo] = (uint8_t)ops.preset;
+      if (TM::LL != 6) TM::sync();
+    }
 #pragma unroll 1
     for (uint32_t ui = u0; ui < u1; ++ui) {
       const Unit un = table_load(&wp->units[ui]);

@@ -184,3 +184,37 @@ def test_prof_names_the_kernels(torch_mod):
     # verify reads z(3), t, c1, d
     assert [nb for _, nb in names] == [10 * 8 * 1024 * 2, 10 * 8 * 1024 * 2, 6 * 8 * 1024 * 2]
     assert len(durs) == 3 and all(v > 0 for v in durs)
+
+
+@pytest.mark.parametrize("N", [512, 1024, 2048])
+@pytest.mark.parametrize("in_kernel", [1, 0])
+def test_verdict_flags_initialised_by_the_launch_or_by_a_fill(torch_mod, N, in_kernel):
+    """Verdict flags start at "ok" either inside the unit kernels (one team per batch entry: RZK_UPT=64 forces that at a
+    small batch, as batches >= 4096 have it) or by a fill launch in front (RZK_PRESET_IN_KERNEL=0): same verdicts, and a
+    stale buffer never leaks through — the flag array is handed over full of garbage both times.
+    check_commit_constraint / check_verify_constraint + the relation: params.rs:102-118, open.rs:167-173."""
+    n, k, l, B = 1, 3, 1, 6
+    ctx = make_ctx(N, n, k, l, env={"RZK_UPT": 64, "RZK_PRESET_IN_KERNEL": in_kernel})
+    P = P_of(ctx)
+    A, x, r, y, d, c, t, z = _open_proof(ctx, B, 4700 + N)
+    # commit side: r of proof 2 beyond the commit bound (norm_2 <= 4 sigma floor(sqrt N), params.rs:102-108)
+    rbad = r.copy()
+    rbad[2, 1, :] = 5 * P.sigma
+    want_ok = [int(O.open_commit(P, A, x[b], rbad[b], y[b])[2]) for b in range(B)]
+    assert want_ok == [1, 1, 0, 1, 1, 1]
+    torch = torch_mod
+    for _ in range(2):   # device path twice into the same (dirty) verdict buffers
+        okd = torch.full((B,), 0xAB, dtype=torch.uint8, device="cuda")
+        cm, tt, okd2 = ctx.open_commit(dev(torch, x), dev(torch, rbad), dev(torch, y))
+        assert okd2.cpu().numpy().tolist() == want_ok
+        del okd
+    assert ctx.open_commit(x, rbad, y)[2].tolist() == want_ok
+    # verify side: z of proof 4 beyond the verify bound, proof 1 with a broken relation
+    zbad = z.copy()
+    zbad[4, 0, :] = 3 * P.sigma
+    tb = t.copy()
+    tb[1, 0, 3] = O.center(int(tb[1, 0, 3]) + 1)
+    want = [int(O.open_verify(P, A, zbad[b], tb[b], c[b], d[b]) == 1) for b in range(B)]
+    assert want == [1, 0, 1, 1, 0, 1]
+    assert ctx.open_verify(zbad, tb, c, d).tolist() == want
+    assert ctx.open_verify(*(dev(torch, v) for v in (zbad, tb, c, d))).cpu().numpy().tolist() == want

@@ -2934,53 +2934,81 @@ eq_kernel_small(const int64_t* __restrict__ a, const int64_t* __restrict__ b, ui
 //   challenge random_polynomial_from_challenge_set (src/challenge_space.rs:12-33): kappa coefficients +-1 at a
 //             uniformly random kappa-subset of the N positions (what shuffling kappa marked slots gives)
 // =============================================================================================
+// One thread = one Philox block = two coefficients = one 16-byte store at a lane-consecutive address (full lines per wave
+// instruction); the polynomial index is a shift (N is a power of two).  pair16: `out` is 16-byte aligned.
+__device__ __forceinline__ void store_pair(int64_t* __restrict__ out, uint64_t c0, uint64_t ncoef, int64_t v0, int64_t v1, bool pair16) {
+  if (pair16 && c0 + 1 < ncoef) {
+    st_stream(reinterpret_cast<int4*>(out + c0), make_int4((int32_t)v0, (int32_t)(v0 >> 32), (int32_t)v1, (int32_t)(v1 >> 32)));
+  } else {
+    out[c0] = v0;
+    if (c0 + 1 < ncoef) out[c0 + 1] = v1;
+  }
+}
+
 __global__ void __launch_bounds__(256)
-sample_uniform_kernel(int64_t* __restrict__ out, uint64_t ncoef, uint32_t n_ring, uint64_t seed, uint32_t stream,
+sample_uniform_kernel(int64_t* __restrict__ out, uint64_t ncoef, uint32_t log_ring, uint64_t seed, uint32_t stream,
                       uint32_t bound) {
   const uint32_t range = 2u * bound + 1u;   // bound <= (2^32 - 2) / 2
-  for (uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x; u * 4 < ncoef; u += (uint64_t)gridDim.x * 256) {
-    const uint64_t c0 = u * 4;
-    const uint64_t poly = c0 / n_ring;
-    const uint32_t blk = (uint32_t)((c0 - poly * n_ring) / 4);
-    const Philox4 a = sampler_block(seed, stream, poly, 2 * blk), b = sampler_block(seed, stream, poly, 2 * blk + 1);
-    int64_t v[4];
-    v[0] = (int64_t)uniform_below(a.v[0], a.v[1], range) - (int64_t)bound;
-    v[1] = (int64_t)uniform_below(a.v[2], a.v[3], range) - (int64_t)bound;
-    v[2] = (int64_t)uniform_below(b.v[0], b.v[1], range) - (int64_t)bound;
-    v[3] = (int64_t)uniform_below(b.v[2], b.v[3], range) - (int64_t)bound;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (c0 + i < ncoef) out[c0 + i] = v[i];
+  const bool pair16 = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+  const uint32_t pair_mask = (1u << (log_ring - 1)) - 1u;
+  for (uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x; u * 2 < ncoef; u += (uint64_t)gridDim.x * 256) {
+    const uint64_t poly = u >> (log_ring - 1);
+    const uint32_t blk = (uint32_t)u & pair_mask;   // block `blk` of a polynomial gives its coefficients 2 blk, 2 blk + 1
+    const Philox4 a = sampler_block(seed, stream, poly, blk);
+    const int64_t v0 = (int64_t)uniform_below(a.v[0], a.v[1], range) - (int64_t)bound;
+    const int64_t v1 = (int64_t)uniform_below(a.v[2], a.v[3], range) - (int64_t)bound;
+    store_pair(out, u * 2, ncoef, v0, v1, pair16);
   }
 }
 
+// Box-Muller, one pair per Philox block.  F32 (sigma < 2^19: every sigma the parameter sets produce): the radius from a
+// 64-bit uniform through exponent + v_log_f32 of the 24-bit mantissa (no cancellation: the tail reaches 9.4 sigma), the
+// angle from a 32-bit uniform through sincospif; absolute error of a sample < 0.1 before the truncation toward zero —
+// statistical parity as for the generator itself.  Larger sigma (up to the 2^26 the entry point admits) keeps the
+// double-precision form, whose samples need more than 24 bits.
+template <bool F32>
 __global__ void __launch_bounds__(256)
-sample_gauss_kernel(int64_t* __restrict__ out, uint64_t ncoef, uint32_t n_ring, uint64_t seed, uint32_t stream,
+sample_gauss_kernel(int64_t* __restrict__ out, uint64_t ncoef, uint32_t log_ring, uint64_t seed, uint32_t stream,
                     double sigma) {
-  for (uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x; u * 4 < ncoef; u += (uint64_t)gridDim.x * 256) {
-    const uint64_t c0 = u * 4;
-    const uint64_t poly = c0 / n_ring;
-    const uint32_t blk = (uint32_t)((c0 - poly * n_ring) / 4);
-    const Philox4 a = sampler_block(seed, stream, poly, 2 * blk), b = sampler_block(seed, stream, poly, 2 * blk + 1);
-    // two Box-Muller pairs from 53-bit uniforms in (0,1]
-    const double k = 1.0 / 9007199254740992.0;   // 2^-53
-    const double u0 = ((double)((((uint64_t)a.v[0] << 32) | a.v[1]) >> 11) + 1.0) * k;
-    const double u1 = (double)((((uint64_t)a.v[2] << 32) | a.v[3]) >> 11) * k;
-    const double u2 = ((double)((((uint64_t)b.v[0] << 32) | b.v[1]) >> 11) + 1.0) * k;
-    const double u3 = (double)((((uint64_t)b.v[2] << 32) | b.v[3]) >> 11) * k;
-    const double r0 = sigma * sqrt(-2.0 * log(u0)), r1 = sigma * sqrt(-2.0 * log(u2));
-    double s0, c0d, s1, c1d;
-    sincospi(2.0 * u1, &s0, &c0d);
-    sincospi(2.0 * u3, &s1, &c1d);
-    const double g[4] = {r0 * c0d, r0 * s0, r1 * c1d, r1 * s1};
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (c0 + i < ncoef) out[c0 + i] = (int64_t)g[i];   // conversion truncates toward zero, like I::from_f64
+  const bool pair16 = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+  const uint32_t pair_mask = (1u << (log_ring - 1)) - 1u;
+  const float sigf = (float)sigma;
+  for (uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x; u * 2 < ncoef; u += (uint64_t)gridDim.x * 256) {
+    const uint64_t poly = u >> (log_ring - 1);
+    const uint32_t blk = (uint32_t)u & pair_mask;
+    const Philox4 a = sampler_block(seed, stream, poly, blk);
+    int64_t v0, v1;
+    if (F32) {
+      // u0 = X 2^-64, X = a.v[0]:a.v[1] (X = 0, probability 2^-64, is taken as 1): log2 u0 = log2 m - 1 - lz, m in [1,2)
+      uint64_t X = ((uint64_t)a.v[0] << 32) | a.v[1];
+      X = X ? X : 1ull;
+      const int lz = __builtin_clzll(X);
+      const uint32_t top = (uint32_t)((X << lz) >> 40);                  // 24 bits, top bit set
+      const float m = (float)top * (1.0f / 8388608.0f);                  // exact: [1, 2)
+      const float l2 = __log2f(m) - (float)(lz + 1);                     // <= -2^-24 (m = 2 - 2^-23, lz = 0)
+      const float r = sigf * __fsqrt_rn(-1.3862943611198906f * l2);      // sigma sqrt(-2 ln u0)
+      float sn, cs;
+      sincospif((float)a.v[2] * (2.0f / 4294967296.0f), &sn, &cs);       // angle 2 pi u1
+      v0 = (int64_t)(r * cs);                                            // conversion truncates toward zero, like I::from_f64
+      v1 = (int64_t)(r * sn);
+    } else {
+      const double k = 1.0 / 9007199254740992.0;   // 2^-53: 53-bit uniforms, u0 in (0,1]
+      const double u0 = ((double)((((uint64_t)a.v[0] << 32) | a.v[1]) >> 11) + 1.0) * k;
+      const double u1 = (double)((((uint64_t)a.v[2] << 32) | a.v[3]) >> 11) * k;
+      const double r0 = sigma * sqrt(-2.0 * log(u0));
+      double s0, c0d;
+      sincospi(2.0 * u1, &s0, &c0d);
+      v0 = (int64_t)(r0 * c0d);
+      v1 = (int64_t)(r0 * s0);
+    }
+    store_pair(out, u * 2, ncoef, v0, v1, pair16);
   }
 }
 
-// one wavefront per polynomial: lane 0 picks the kappa-subset (Floyd's algorithm on an LDS bitmap-like byte map),
-// then all lanes write the N coefficients
+// one wavefront per polynomial: Floyd's algorithm for a uniform kappa-subset.  Lane t draws step t's candidate (its own
+// Philox block half) in parallel; only the collision rule "candidate already marked -> take j" is sequential, walked
+// with readlane over an LDS byte map (same picks, same output as a one-lane loop).  All lanes then write the N
+// coefficients, two per 16-byte store.
 __global__ void __launch_bounds__(256)
 sample_challenge_kernel(int64_t* __restrict__ out, uint64_t npoly, uint32_t n_ring, uint64_t seed, uint32_t stream,
                         uint32_t kappa) {
@@ -2988,24 +3016,40 @@ sample_challenge_kernel(int64_t* __restrict__ out, uint64_t npoly, uint32_t n_ri
   const int lane = threadIdx.x & 63;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int8_t* mark = reinterpret_cast<int8_t*>(smem) + (size_t)wave * n_ring;
+  uint32_t* mark_w = reinterpret_cast<uint32_t*>(mark);   // n_ring is a multiple of 4
+  const uint32_t kap = kappa < n_ring ? kappa : n_ring;
+  const bool pair16 = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
   for (uint64_t poly = (uint64_t)blockIdx.x * 4 + wave; poly < npoly; poly += (uint64_t)gridDim.x * 4) {
-    for (uint32_t i = lane; i < n_ring; i += 64) mark[i] = 0;
+    for (uint32_t i = lane; i < n_ring / 4; i += 64) mark_w[i] = 0;
     wave_sync();
-    if (lane == 0) {
-      const uint32_t kap = kappa < n_ring ? kappa : n_ring;
-      Philox4 r{};
-      for (uint32_t t = 0; t < kap; ++t) {   // Floyd: a uniform kap-subset of [0, n_ring)
-        if ((t & 1) == 0) r = sampler_block(seed, stream, poly, t >> 1);
-        const uint32_t j = n_ring - kap + t;
-        const uint32_t w0 = r.v[(t & 1) * 2], w1 = r.v[(t & 1) * 2 + 1];
-        const uint32_t pick = uniform_below(w0, w1 & ~1u, j + 1);
-        const uint32_t pos = mark[pick] ? j : pick;
-        mark[pos] = (w1 & 1u) ? 1 : -1;   // random_bool(0.5): +1 / -1
+    for (uint32_t t0 = 0; t0 < kap; t0 += 64) {
+      const uint32_t t = t0 + lane;
+      const Philox4 r = sampler_block(seed, stream, poly, t >> 1);
+      const uint32_t w0 = (t & 1) ? r.v[2] : r.v[0], w1 = (t & 1) ? r.v[3] : r.v[1];
+      const uint32_t j = n_ring - kap + t;                               // (lanes beyond kap: unused)
+      const uint32_t pick = uniform_below(w0, w1 & ~1u, j + 1);
+      const int32_t sign = (w1 & 1u) ? 1 : -1;                           // random_bool(0.5): +1 / -1
+      const uint32_t m = kap - t0 < 64u ? kap - t0 : 64u;
+#pragma unroll 1
+      for (uint32_t e = 0; e < m; ++e) {
+        const uint32_t pk = (uint32_t)__builtin_amdgcn_readlane((int)pick, (int)e);
+        const uint32_t jj = (uint32_t)__builtin_amdgcn_readlane((int)j, (int)e);
+        const int32_t sg = __builtin_amdgcn_readlane(sign, (int)e);
+        const uint32_t pos = mark[pk] ? jj : pk;
+        wave_sync();
+        if (lane == 0) mark[pos] = (int8_t)sg;
+        wave_sync();
       }
     }
-    wave_sync();
     int64_t* dst = out + poly * n_ring;
-    for (uint32_t i = lane; i < n_ring; i += 64) dst[i] = (int64_t)mark[i];
+    if (pair16) {
+      for (uint32_t i = 2 * lane; i < n_ring; i += 128) {
+        const int32_t a0 = mark[i], a1 = mark[i + 1];
+        st_stream(reinterpret_cast<int4*>(dst + i), make_int4(a0, a0 >> 31, a1, a1 >> 31));
+      }
+    } else {
+      for (uint32_t i = lane; i < n_ring; i += 64) dst[i] = (int64_t)mark[i];
+    }
     wave_sync();
   }
 }
@@ -3372,21 +3416,33 @@ int launch_fill_u8(const LaunchCfg& cfg, uint8_t* p, uint8_t value, uint64_t n) 
   return 0;
 }
 
+static inline uint32_t log2_u32(uint32_t v) {
+  uint32_t l = 0;
+  while ((1u << l) < v) ++l;
+  return l;
+}
 int launch_sample_uniform(const LaunchCfg& cfg, int64_t* out, uint64_t npoly, uint32_t n_ring, uint64_t seed,
                           uint32_t stream, uint32_t bound) {
   if (npoly == 0) return 0;
+  if (n_ring < 2 || (n_ring & (n_ring - 1))) return -1;
   const uint64_t ncoef = npoly * n_ring;
-  hipLaunchKernelGGL(sample_uniform_kernel, dim3(grid_for((ncoef + 3) / 4, cfg.num_cus, 256, 16)), dim3(256), 0,
-                     (hipStream_t)cfg.stream, out, ncoef, n_ring, seed, stream, bound);
+  hipLaunchKernelGGL(sample_uniform_kernel, dim3(grid_for((ncoef + 1) / 2, cfg.num_cus, 256, 16)), dim3(256), 0,
+                     (hipStream_t)cfg.stream, out, ncoef, log2_u32(n_ring), seed, stream, bound);
   RZK_LAUNCH_CHECK();
   return 0;
 }
 int launch_sample_gauss(const LaunchCfg& cfg, int64_t* out, uint64_t npoly, uint32_t n_ring, uint64_t seed,
                         uint32_t stream, double sigma) {
   if (npoly == 0) return 0;
+  if (n_ring < 2 || (n_ring & (n_ring - 1))) return -1;
   const uint64_t ncoef = npoly * n_ring;
-  hipLaunchKernelGGL(sample_gauss_kernel, dim3(grid_for((ncoef + 3) / 4, cfg.num_cus, 256, 16)), dim3(256), 0,
-                     (hipStream_t)cfg.stream, out, ncoef, n_ring, seed, stream, sigma);
+  const dim3 grid(grid_for((ncoef + 1) / 2, cfg.num_cus, 256, 16));
+  if (sigma < 524288.0)   // 9.4 sigma < 2^23: single precision carries every sample with an error far below 1
+    hipLaunchKernelGGL(sample_gauss_kernel<true>, grid, dim3(256), 0, (hipStream_t)cfg.stream, out, ncoef, log2_u32(n_ring), seed,
+                       stream, sigma);
+  else
+    hipLaunchKernelGGL(sample_gauss_kernel<false>, grid, dim3(256), 0, (hipStream_t)cfg.stream, out, ncoef, log2_u32(n_ring), seed,
+                       stream, sigma);
   RZK_LAUNCH_CHECK();
   return 0;
 }

@@ -202,6 +202,29 @@ int emul_polymul(int logn, int np, uint64_t q, const int64_t* a, const int64_t* 
   }
   return -1;
 }
+// CPU statement of what the device-side samplers draw for polynomial `poly` of a call (rzk_kernels.hip: one Philox block
+// per coefficient pair; Floyd's subset algorithm for the challenge): the kernels must give exactly these values.
+void emul_sample_uniform(uint64_t seed, uint32_t stream, uint64_t poly, uint32_t N, uint32_t bound, int64_t* out) {
+  const uint32_t range = 2u * bound + 1u;
+  for (uint32_t blk = 0; blk < N / 2; ++blk) {
+    const Philox4 a = sampler_block(seed, stream, poly, blk);
+    out[2 * blk] = (int64_t)uniform_below(a.v[0], a.v[1], range) - (int64_t)bound;
+    out[2 * blk + 1] = (int64_t)uniform_below(a.v[2], a.v[3], range) - (int64_t)bound;
+  }
+}
+void emul_sample_challenge(uint64_t seed, uint32_t stream, uint64_t poly, uint32_t N, uint32_t kappa, int64_t* out) {
+  for (uint32_t i = 0; i < N; ++i) out[i] = 0;
+  const uint32_t kap = kappa < N ? kappa : N;
+  Philox4 r{};
+  for (uint32_t t = 0; t < kap; ++t) {   // Floyd: a uniform kap-subset of [0, N)
+    if ((t & 1) == 0) r = sampler_block(seed, stream, poly, t >> 1);
+    const uint32_t j = N - kap + t;
+    const uint32_t w0 = r.v[(t & 1) * 2], w1 = r.v[(t & 1) * 2 + 1];
+    const uint32_t pick = uniform_below(w0, w1 & ~1u, j + 1);
+    const uint32_t pos = out[pick] ? j : pick;
+    out[pos] = (w1 & 1u) ? 1 : -1;
+  }
+}
 void emul_philox(const uint32_t* ctr, const uint32_t* key, uint32_t* out) {
   const Philox4 r = philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
   for (int i = 0; i < 4; ++i) out[i] = r.v[i];

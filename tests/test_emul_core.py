@@ -20,8 +20,8 @@ Q = O.Q_DEFAULT
 HALF = (Q - 1) // 2
 
 
-@pytest.fixture(scope="module")
-def emul():
+def load_emul():
+    """Builds (when stale) and loads the CPU emulator; also used by GPU tests that pin kernels to its functions."""
     so = os.path.join(EMUL_DIR, "libemul.so")
     srcs = [os.path.join(EMUL_DIR, "emul.cpp"),
             os.path.join(HERE, "..", "ring_zk_amd", "csrc", "rzk_rng.h"),
@@ -35,6 +35,11 @@ def emul():
     L.emul_psi.restype = C.c_uint32
     L.emul_capacity.restype = C.c_double
     return L
+
+
+@pytest.fixture(scope="module")
+def emul():
+    return load_emul()
 
 
 def _u32p(a):

@@ -156,3 +156,40 @@ def test_generated_key_has_the_reference_structure(shape):
     c_ref, ok_ref = O.commit(P, A, x[0], r[0])
     assert np.array_equal(cm[0], c_ref) and bool(ok[0]) == ok_ref
     assert O.commitment_verify(P, A, cm[0], x[0], r[0])
+
+
+def test_uniform_and_challenge_kernels_match_their_cpu_statement(ctx):
+    """The counter-based samplers are a function of (seed, stream, polynomial): tests/emul/emul.cpp states that function
+    on the CPU (Philox block per coefficient pair; Floyd's kappa-subset for the challenge, challenge_space.rs:12-33) and
+    the kernels — which draw in parallel, two coefficients per thread / one Floyd step per lane — must reproduce it
+    bit for bit, whatever the launch shape and the alignment of the output buffer."""
+    import ctypes as C
+
+    import torch
+
+    from test_emul_core import load_emul
+
+    L = load_emul()
+    N = 1024
+    p64 = lambda a: a.ctypes.data_as(C.POINTER(C.c_int64))
+    want = np.empty(N, dtype=np.int64)
+    for bound, stream in ((1, 3), (HALF, 4), (12345, 5)):
+        got = ctx.sample_uniform(77, stream, bound, (9,)).cpu().numpy()
+        for poly in (0, 5, 8):
+            L.emul_sample_uniform(C.c_uint64(77), C.c_uint32(stream), C.c_uint64(poly), C.c_uint32(N), C.c_uint32(bound), p64(want))
+            assert np.array_equal(got[poly], want), (bound, poly)
+    got = ctx.sample_challenge(78, 2, (70,)).cpu().numpy()
+    for poly in (0, 1, 63, 69):
+        L.emul_sample_challenge(C.c_uint64(78), C.c_uint32(2), C.c_uint64(poly), C.c_uint32(N), C.c_uint32(ctx.kappa), p64(want))
+        assert np.array_equal(got[poly], want), poly
+    # an output buffer that is only 8-byte aligned takes the 8-byte store path: same values
+    buf = torch.empty(3 * N + 1, dtype=torch.int64, device="cuda")
+    view = buf[1:]
+    assert view.data_ptr() % 16 == 8
+    L2 = ctx._L
+    assert L2.rzk_sample_challenge_dev(ctx._h, 78, 2, C.c_void_p(view.data_ptr()), 3) == 0
+    assert np.array_equal(view.cpu().numpy().reshape(3, N), got[:3])
+    assert L2.rzk_sample_uniform_dev(ctx._h, 77, 3, 1, C.c_void_p(view.data_ptr()), 3) == 0
+    assert np.array_equal(view.cpu().numpy().reshape(3, N), ctx.sample_uniform(77, 3, 1, (3,)).cpu().numpy())
+    assert L2.rzk_sample_gauss_dev(ctx._h, 79, 0, C.c_double(1000.0), C.c_void_p(view.data_ptr()), 3) == 0
+    assert np.array_equal(view.cpu().numpy().reshape(3, N), ctx.sample_gauss(79, 0, 1000.0, (3,)).cpu().numpy())

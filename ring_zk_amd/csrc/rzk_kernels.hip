@@ -596,6 +596,9 @@ __device__ __forceinline__ void load_pairs(int32_t* v, const int64_t* __restrict
 #ifndef RZK_SHIFT_H_MEM
 #define RZK_SHIFT_H_MEM 16   // ... for the rotation terms inside the row kernels (sums go to the wave's scratch line)
 #endif
+#ifndef RZK_SHIFT_H_MEM_PAIR
+#define RZK_SHIFT_H_MEM_PAIR 8   // ... of a two-wavefront team (16 measured slower: verify at N = 2048 189 vs 184 us, 40 vs 8 bytes of scratch)
+#endif
 // walk the non-zero coefficients of the multiplier (registers a[], lane-distributed in layout PAIR) and add
 // the rotations into IN outputs of every lane; `ext` already points at the first of them
 template <int LOGN, bool PAIR, int IN>
@@ -729,7 +732,7 @@ __device__ __forceinline__ void shift_product(uint32_t* res, bool fresh, bool mi
   if (LL != 6) asm volatile("" : "+v"(lane));   // per call: keeps the thread's 64-bit line / image addresses out of the kernel prologue
   using S = ShiftGeo<LOGN, PAIR, LL>;
   constexpr int E = S::E;
-  constexpr int HW = TO_MEM ? RZK_SHIFT_H_MEM : RZK_SHIFT_H;   // (the in-kernel rotation terms run with nothing else live)
+  constexpr int HW = TO_MEM ? (LL == 6 ? RZK_SHIFT_H_MEM : RZK_SHIFT_H_MEM_PAIR) : RZK_SHIFT_H;   // (the in-kernel rotation terms run with nothing else live)
   constexpr int H = HW < E ? HW : E;   // outputs per scan; chunk c covers registers c*H .. c*H+H-1
   constexpr int NCH = E / H;
   constexpr bool LIST = LL != 6;

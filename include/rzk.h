@@ -260,7 +260,9 @@ double rzk_bench_ntt_forward_dev(rzk_ctx* ctx, int prime, const uint32_t* in, ui
  *   uniform   random_polynomial_within (src/polynomial.rs:14-25): coefficients uniform in [-bound, bound],
  *             1 <= bound <= (q-1)/2  (commit randomness r: bound = b, commit.rs:101; key / message: (q-1)/2)
  *   gauss     random_polynomial_in_normal_distribution (src/polynomial.rs:28-44): (i64) N(0, sigma), truncated
- *             toward zero like I::from_f64; y of the provers: sigma = rzk_sigma(ctx) (open.rs:88-94)
+ *             toward zero like I::from_f64; y of the provers: sigma = rzk_sigma(ctx) (open.rs:88-94).  Box-Muller on a
+ *             64-bit uniform (tail to 9.4 sigma); evaluated in single precision for sigma < 2^19 (sample error < 0.1
+ *             before the truncation: every parameter set of the reference), in double precision up to 2^26
  *   challenge random_polynomial_from_challenge_set (src/challenge_space.rs:12-33): exactly kappa coefficients
  *             +-1 (kappa of the context) at a uniformly random subset of positions, zeros elsewhere */
 int rzk_sample_uniform_dev(rzk_ctx* ctx, uint64_t seed, uint32_t stream, uint64_t bound, int64_t* out, size_t count);

@@ -181,9 +181,15 @@ __device__ __forceinline__ float uniform_f32(float x) {
 //             sum is two wave reductions exchanged through two LDS words, added in the same order by both waves, so
 //             that both take bit-identical decisions (prime counts, exact-path switches) and never part ways
 //             before a barrier.
+#ifndef RZK_WAVE_TPB
+#define RZK_WAVE_TPB 4   // one-wavefront teams per workgroup (experiment: 1 lets a CU hold 19 instead of 16 teams of unit_kernel's 8.1 KB)
+#endif
+#ifndef RZK_UNIT_MIN_WAVES
+#define RZK_UNIT_MIN_WAVES 1   // waves per SIMD unit_kernel<.., false, ..> of one-wavefront teams is compiled for (experiment: 5)
+#endif
 struct WaveTeam {
   static constexpr int LL = 6;
-  static constexpr int kTeamsPerBlock = 4;
+  static constexpr int kTeamsPerBlock = RZK_WAVE_TPB;
   __device__ __forceinline__ static void sync() { wave_sync(); }
   __device__ __forceinline__ static float sum_f32(float v) { return wave_sum_f32(v); }
   __device__ __forceinline__ static uint64_t sum_u56(uint64_t v) { return wave_sum_u56(v); }
@@ -1290,7 +1296,7 @@ __device__ __forceinline__ void finish_row(uint32_t* u, const Program* __restric
 // two-wavefront team (PairTeam, N = 2048).  Teams of two are compiled for 4 waves per SIMD (<= 128 VGPRs: 16
 // coefficients per thread, the budget of the N = 1024 kernels).
 template <int LOGN, bool HAS_VEC, bool HAS_SHIFT, class TM = WaveTeam>
-__global__ void __launch_bounds__(TM::kTeamsPerBlock << TM::LL, ((LOGN <= 10 && HAS_VEC) || TM::LL == 7 ? 4 : 1))   // vector x vector variants: hold the 4 waves per SIMD the LDS allows
+__global__ void __launch_bounds__(TM::kTeamsPerBlock << TM::LL, ((LOGN <= 10 && HAS_VEC) || TM::LL == 7 ? 4 : RZK_UNIT_MIN_WAVES))   // vector x vector variants: hold the 4 waves per SIMD the LDS allows
 unit_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__ wp, const Operands ops,
             const uint32_t* __restrict__ key_ntt, const double* __restrict__ key_l2, const DevTables* __restrict__ Tp,
             const uint32_t* __restrict__ tw_all, uint32_t* __restrict__ scratch, uint8_t* __restrict__ flags,
@@ -3101,7 +3107,7 @@ static int launch_units_t(const LaunchCfg& cfg, const Program* d_prog, const Wav
     if (e != hipSuccess) return (int)e;
   }
   // scratch sizing: at most num_cus * 32 team lines; every team walks its tasks with a grid stride
-  const unsigned grid = grid_for(ntasks, cfg.num_cus, TPB, 8);
+  const unsigned grid = grid_for(ntasks, cfg.num_cus, TPB, TM::LL == 6 ? 32 / TPB : 8);
   hipLaunchKernelGGL((unit_kernel<LOGN, HAS_VEC, HAS_SHIFT, TM>), dim3(grid), dim3(TPB << TM::LL), lds, (hipStream_t)cfg.stream,
                      d_prog, d_wp, ops, d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks, upt, tpe, wpt);
   RZK_LAUNCH_CHECK();
@@ -3120,7 +3126,7 @@ static int launch_units_io_t(const LaunchCfg& cfg, const Program* d_prog, const 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  const unsigned grid = grid_for(ntasks, cfg.num_cus, TPB, 8);
+  const unsigned grid = grid_for(ntasks, cfg.num_cus, TPB, TM::LL == 6 ? 32 / TPB : 8);
   hipLaunchKernelGGL((unit_io_kernel<LOGN, HAS_SHIFT, TM>), dim3(grid), dim3(TPB << TM::LL), lds, (hipStream_t)cfg.stream,
                      d_prog, d_wp, ops, d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks, upt, tpe, wpt);
   RZK_LAUNCH_CHECK();
@@ -3139,7 +3145,7 @@ static int launch_rows_t(const LaunchCfg& cfg, const Program* d_prog, const Oper
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  const unsigned grid = grid_for(ntasks, cfg.num_cus, TPB, 8);   // <= num_cus * 8 blocks (scratch sizing)
+  const unsigned grid = grid_for(ntasks, cfg.num_cus, TPB, TM::LL == 6 ? 32 / TPB : 8);   // <= 32 team lines per CU (scratch sizing)
   hipLaunchKernelGGL((row_kernel<LOGN, HAS_SHIFT, TM>), dim3(grid), dim3(TPB << TM::LL), lds, (hipStream_t)cfg.stream, d_prog, ops,
                      d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks);
   RZK_LAUNCH_CHECK();

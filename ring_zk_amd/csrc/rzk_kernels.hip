@@ -181,6 +181,9 @@ __device__ __forceinline__ float uniform_f32(float x) {
 //             sum is two wave reductions exchanged through two LDS words, added in the same order by both waves, so
 //             that both take bit-identical decisions (prime counts, exact-path switches) and never part ways
 //             before a barrier.
+#ifndef RZK_ROW_ROTATE
+#define RZK_ROW_ROTATE 1   // row_kernel: rotate the row index per trip when the task stride is a multiple of the row count
+#endif
 #ifndef RZK_WAVE_TPB
 #define RZK_WAVE_TPB 4   // one-wavefront teams per workgroup (experiment: 1 lets a CU hold 19 instead of 16 teams of unit_kernel's 8.1 KB)
 #endif
@@ -1952,9 +1955,20 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
   const bool trusted = ops.trusted != 0;
   const uint32_t nrows = prog->nrows;
 
-  for (uint32_t task = blockIdx.x * TPB + wave; task < ntasks; task += gridDim.x * TPB) {
+  // When the task stride is a multiple of the row count a team would meet the same row of the program on every trip —
+  // and with it the same SIMD (wave i of a workgroup lands on SIMD i): rows of different cost (Linear's verifier: two
+  // relation rows with a rotation term, a key row, a vector x vector row) then load the SIMDs unevenly.  The row index
+  // is rotated by the trip count in that case (a permutation inside each batch entry).
+  const uint32_t stride = gridDim.x * TPB;
+  const bool rotate_rows = RZK_ROW_ROTATE && nrows > 1 && stride % nrows == 0;
+  uint32_t trip = 0;
+  for (uint32_t task = blockIdx.x * TPB + wave; task < ntasks; task += stride, ++trip) {
     const uint32_t b = task / nrows;
-    const uint32_t rowi = task - b * nrows;
+    uint32_t rowi = task - b * nrows;
+    if (rotate_rows) {
+      rowi += trip % nrows;
+      rowi = rowi >= nrows ? rowi - nrows : rowi;
+    }
     const uint32_t bo = ops.group > 1 ? b / ops.group : b;
     const Row row = table_load(&prog->rows[rowi]);
     const bool has_shift = HAS_SHIFT && row.nshift > 0;

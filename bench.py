@@ -554,17 +554,21 @@ def main():
                             "frac_of_hbm_peak": e["bytes"] / (e["us"] * 1e-6) / 1e9 / HBM_PEAK_GBS}
                        for nm, e in sorted(per_kernel.items(), key=lambda kv: -kv[1]["us"])}
         traffic, traffic_src = None, None
-        pmc_path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-        if os.path.exists(pmc_path):
+        # HBM bytes per launch of the dominant kernel: from the committed PMC passes of this same configuration
+        # (profiles/r03_<config>_pmc_traffic.json, tools/collect_evidence.sh), matched by workload key and kernel name
+        import glob
+        key = f"{args.workload}-{N}-{args.shape}"
+        for pmc_path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*pmc_traffic.json"))):
             try:
                 pj = json.load(open(pmc_path))
-                ent = pj.get("kernels", {}).get(dom_name) if pj.get("workload") == f"{args.workload}-{N}-{args.shape}" else None
-                if ent:
-                    traffic = ent.get("hbm_bytes_per_launch")
-                    traffic_src = "imported from profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of " \
-                                  "this same command, corrected as the guide prescribes; not measured in this run)"
             except Exception:
-                traffic = None
+                continue
+            ent = pj.get("kernels", {}).get(dom_name) if pj.get("workload") == key else None
+            if ent and ent.get("hbm_bytes_per_launch"):
+                traffic = ent.get("hbm_bytes_per_launch")
+                traffic_src = f"imported from profiles/{os.path.basename(pmc_path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes " \
+                              "of this same command, corrected as the guide prescribes; not measured in this run)"
+                break
         roofline = {
             "kernel": dom_name,
             "bound": "hbm",
@@ -586,7 +590,7 @@ def main():
                       "frac": cycle_bytes / (cycle_us * 1e-6) / 1e9 / HBM_PEAK_GBS if cycle_us else None},
             "launches_timed": int(launches),
         }
-        rot = N <= 1024
+        rot = True   # challenge products as rotations at every ring degree (N = 2048: two-wavefront teams, round 3)
         upp = min_transform_units(args.workload, n, k, l, V, rot)
         bpu = (N // 2) * (N.bit_length() - 1)
         brate = upp * bpu * value / max(world, 1)
@@ -595,7 +599,7 @@ def main():
                  "butterflies_per_s_per_gpu": brate, "butterfly_peak": BUTTERFLY_PEAK,
                  "frac_of_butterfly_peak": brate / BUTTERFLY_PEAK,
                  "note": "minimum transform units of the design (operands once per prime and program, rows once per prime; "
-                         "rotations instead of transforms for challenge products at N <= 1024) x (N/2) log2 N butterflies, "
+                         "rotations instead of transforms for challenge products) x (N/2) log2 N butterflies, "
                          "against the measured chip-wide butterfly rate (integer-VALU ceiling)"}
         # stand-alone batched forward NTT (one residue polynomial = 2*N*4 algorithmic bytes)
         # 65536 x 4 KiB in + the same out = 512 MiB per launch: beyond the 256 MiB Infinity Cache

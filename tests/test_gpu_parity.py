@@ -741,3 +741,37 @@ def test_canonicalize(torch_mod):
     assert np.array_equal(ctx.canonicalize(a), want)
     assert np.array_equal(ctx.canonicalize(dev(torch_mod, a)).cpu().numpy(), want)
     assert np.array_equal(ctx.canonicalize(want), want)      # idempotent
+
+
+@pytest.mark.parametrize("nnz", [1, 255, 256, 257, 512, 2047])
+def test_rotation_list_round_boundaries_n2048(torch_mod, nnz):
+    """N = 2048: a two-wavefront team walks the multiplier's non-zeros from a list of 256 entries per round
+    (rzk_core.h kShiftListCap); counts at and around the round boundary, split unevenly between the two wavefronts
+    (positions drawn from the low half of the ring only, from the high half only, and from both), must all give the
+    exact product — response rows (shift_row_kernel) and the verifier's rotation term (unit_kernel)."""
+    N, n, k, l = 2048, 1, 3, 1
+    ctx = ctx_for(N, n, k, l)
+    P = _P(ctx)
+    rng = np.random.default_rng(7000 + nnz)
+    A = synth.key(rng, N, n, k, l)
+    ctx.load_key(A)
+    B = 3
+    d = np.zeros((B, N), dtype=np.int64)
+    pools = [np.arange(N), np.arange(0, N // 2) if nnz <= N // 2 else np.arange(N), np.arange(N // 2, N) if nnz <= N // 2 else np.arange(N)]
+    for b in range(B):
+        pos = rng.choice(pools[b], nnz, replace=False)
+        d[b, pos] = rng.choice([-1, 1], nnz)
+    y = synth.gauss(rng, (B, k, N), P.sigma)
+    r = synth.small(rng, (B, k, N))
+    z = ctx.open_response(y, r, d)
+    for b in range(B):
+        assert np.array_equal(z[b], O.open_response(P, y[b], r[b], d[b])), b
+    zs = synth.gauss(rng, (B, k, N), P.sigma // 4)
+    c = synth.uniform(rng, (B, n + l, N))
+    t = np.empty((B, n, N), dtype=np.int64)
+    for b in range(B):
+        lhs = O.mat_dot(A[:n], zs[b][:, None, :])
+        t[b] = O.mat_sub(lhs, O.mat_cmul(c[b, :n][:, None, :], d[b]))[:, 0, :]
+    assert ctx.open_verify(zs, t, c, d).tolist() == [1] * B
+    t[1, 0, N - 1] = O.center(int(t[1, 0, N - 1]) + 1)
+    assert ctx.open_verify(zs, t, c, d).tolist() == [1, 0, 1]

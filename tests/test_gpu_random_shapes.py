@@ -6,6 +6,8 @@ n + l + 1 (several random columns in a2'), n = l in 1..3, ragged batch sizes (1,
 the knobs switch — so that an indexing slip which happens to cancel at (1,3,1) or (4,9,4) still shows.
 Reference: src/commit.rs:33-60,109-125, src/prove/open.rs:80-174, linear.rs:82-250, sum.rs:99-320.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -28,6 +30,7 @@ KNOBS = [
     {"RZK_PAIR_POLY": 0},   # N = 2048: one wavefront per polynomial (the round-2 kernels) instead of two
     {"RZK_UNIT_IO": 1},     # key-product programs through unit_io_kernel at every N (default: N = 512 only)
     {"RZK_UNIT_IO": 0},     # ... and through unit_kernel at N = 512
+    {"RZK_UPT": 64, "RZK_PRESET_IN_KERNEL": 0},   # one team per entry, verdict flags preset by a fill launch (default: by the team)
 ]
 
 
@@ -72,7 +75,12 @@ def check_linear_cycle(ctx, A, B, seed):
     assert acc.tolist() == [1] * B and acct.tolist() == [1] * (B - 1) + [0]
 
 
-@pytest.mark.parametrize("seed", range(40))
+# RZK_SWEEP_CASES / RZK_SWEEP_FIRST: a longer soak over other seeds (e.g. 400 cases from seed 1000: ~10 min on the GPU box)
+_SWEEP_N = int(os.environ.get("RZK_SWEEP_CASES", "40"))
+_SWEEP_0 = int(os.environ.get("RZK_SWEEP_FIRST", "0"))
+
+
+@pytest.mark.parametrize("seed", range(_SWEEP_0, _SWEEP_0 + _SWEEP_N))
 def test_random_shape_all_protocols_vs_oracle(torch_mod, seed):
     cs = draw_case(seed)
     ctx = make_ctx(cs["N"], cs["n"], cs["k"], cs["l"], env=cs["env"])

@@ -122,6 +122,33 @@ DEF_KERNEL_F64(mul_f64, "v_mul_f64 %0, %0, %1")
 DEF_KERNEL_F64(add_f64, "v_add_f64 %0, %0, %1")
 DEF_KERNEL_F64(rndne_f64, "v_rndne_f64 %0, %0")
 
+// packed single precision: two FP32 lanes per 64-bit register pair (what a floating-point modular arithmetic over
+// ~22-bit primes would issue)
+#define DEF_KERNEL_PK32(NAME, ASM)                                                       \
+  __global__ void __launch_bounds__(256) k_##NAME(uint32_t* out, uint32_t seed) {        \
+    uint32_t t = threadIdx.x + blockIdx.x * blockDim.x;                                  \
+    double a0 = 1.0 + t * 1e-9 + seed, a1 = 1.1, a2 = 1.2, a3 = 1.3, a4 = 1.4, a5 = 1.5, \
+           a6 = 1.6, a7 = 1.7;   /* bit patterns only: each double register pair is two floats to the instruction */ \
+    double b = 1.0 + 1e-12 * (t & 255);                                                  \
+    for (int i = 0; i < ITER; ++i) {                                                     \
+      _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                    \
+        asm volatile(ASM : "+v"(a0) : "v"(b));                                           \
+        asm volatile(ASM : "+v"(a1) : "v"(b));                                           \
+        asm volatile(ASM : "+v"(a2) : "v"(b));                                           \
+        asm volatile(ASM : "+v"(a3) : "v"(b));                                           \
+        asm volatile(ASM : "+v"(a4) : "v"(b));                                           \
+        asm volatile(ASM : "+v"(a5) : "v"(b));                                           \
+        asm volatile(ASM : "+v"(a6) : "v"(b));                                           \
+        asm volatile(ASM : "+v"(a7) : "v"(b));                                           \
+      }                                                                                  \
+    }                                                                                    \
+    double r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                                    \
+    out[t] = (uint32_t)__double_as_longlong(r);                                          \
+  }
+DEF_KERNEL_PK32(pk_fma_f32, "v_pk_fma_f32 %0, %0, %1, %0")
+DEF_KERNEL_PK32(pk_mul_f32, "v_pk_mul_f32 %0, %0, %1")
+DEF_KERNEL_PK32(pk_add_f32, "v_pk_add_f32 %0, %0, %1")
+
 // ---- composite butterflies written in plain C++ (what the compiler makes of them) ----
 // Montgomery (R = 2^32) via one 64-bit mad: x*w -> t ; m = lo(t)*pinv ; r = hi(t + m*p) in [0,2p)
 __device__ __forceinline__ uint32_t mont_mul_lazy(uint32_t x, uint32_t w, uint32_t p, uint32_t npinv) {
@@ -278,7 +305,9 @@ int main(int argc, char** argv) {
       {"v_mul_u32_u24", k_mul_u32_u24, 64}, {"v_mul_hi_u32_u24", k_mul_hi_u32_u24, 64},
       {"v_mad_u32_u24", k_mad_u32_u24, 64}, {"v_fma_f64", k_fma_f64, 64},
       {"v_mul_f64", k_mul_f64, 64},         {"v_add_f64", k_add_f64, 64},
-      {"v_rndne_f64", k_rndne_f64, 64},     {"bfly_mont32(mad64)", k_bfly_mont, 8},
+      {"v_rndne_f64", k_rndne_f64, 64},
+      {"v_pk_fma_f32 (2 lanes/op)", k_pk_fma_f32, 64}, {"v_pk_mul_f32", k_pk_mul_f32, 64}, {"v_pk_add_f32", k_pk_add_f32, 64},
+      {"bfly_mont32(mad64)", k_bfly_mont, 8},
       {"bfly_shoup32", k_bfly_shoup, 8},    {"bfly_f64_p50", k_bfly_f64, 8},
       {"bfly_u24", k_bfly_u24, 8},
   };

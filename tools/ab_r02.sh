@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B against the round-2 tree (built by hand into .ab_r02/, not tracked): same box, interleaved runs.
+# A/B against the round-2 tree: same box, interleaved runs.  The tree is not tracked; recreate it with
+#   git worktree add .ab_r02 7622940 && (cd .ab_r02 && python -m ring_zk_amd.build)     (7622940 = end of round 2)
 cd "$(dirname "$0")/.."
 sumline='import json,sys
 for line in sys.stdin:

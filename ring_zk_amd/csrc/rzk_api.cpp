@@ -51,6 +51,8 @@ enum ProgId : int {
   PG_COMMIT_VERIFY,   // variant bit 1: opening has a scalar f       (commit.rs:173-210)
   PG_A1Z,             // w = a1.z (n rows), norm predicate on z fused (bit 0)   } the A1 relation in two steps for
   PG_REL_ROT,         // w - c1(.)d - t == 0, all rotations                      } n >= 2: grouped rows + rotations
+  PG_SUM_D,           // variant = V: D_c = sum_i g_i(.)v_{i,c} - v'_c for the columns c that a2 uses   } sum_i g_i (a2.v_i) - a2.v'
+  PG_SUM_V4,          // a2.D - w2(.)d - u == 0                                                           }   = a2.(sum_i g_i v_i - v')
 };
 
 struct DevProg {
@@ -108,6 +110,7 @@ struct rzk_ctx {
   bool use_pairs = true;               // unit_kernel: pair rows that share their last operand (RZK_PAIRS=0 turns it off, tuning)
   int group_max = 1;                   // rows per group of row_group_kernel (group_max_for; RZK_GROUP_MAX overrides, tuning)
   bool use_shift = true;               // challenge products as signed rotations (shift_row_kernel) instead of transforms
+  int sum_d = -1;                      // Sum proof: a2.(sum_i g_i v_i - v') instead of sum_i g_i (a2.v_i) - a2.v' (-1 = by cost, RZK_SUM_D=0|1 forces)
   bool preset_in_kernel = true;        // verdict flags initialised by the unit kernels themselves where one team owns an entry (RZK_PRESET_IN_KERNEL=0: always a fill launch)
   bool small = false;                  // N < 512: schoolbook kernels (rzk_kernels.hip, "small ring degrees")
   uint32_t r2q = 0;                    // 2^64 mod q
@@ -518,6 +521,27 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
         pb.add(-1, 5, j);
       }
       break;
+    case PG_SUM_D: {  // ops: 0 = vs[V*k] (ys or zs), 1 = gs[V], 2 = vp[k] (yp or zp), 3 = D[k]
+      // a2 is linear and the ring commutative: sum_i g_i (.) (a2.v_i) - a2.v' = a2.(sum_i g_i (.) v_i - v')
+      // (sum.rs:154-160 and 301-308); only the columns a2 has entries in are formed
+      for (uint32_t col = 0; col < k; ++col) {
+        bool used = false;
+        for (uint32_t j = 0; j < l; ++j) used = used || c->key_class[(n + j) * k + col] != KC_ZERO;
+        if (!used) continue;
+        pb.begin_row(3, col, MODE_STORE);
+        for (uint32_t i = 0; i < var; ++i) pb.vec_term(+1, 0, i * k + col, 1, i);
+        pb.add(-1, 2, col);
+      }
+      break;
+    }
+    case PG_SUM_V4:   // ops: 0 = D[k], 1 = w2[l], 2 = d, 3 = u[l] : a2.D - w2(.)d - u == 0   (sum.rs:301-319)
+      for (uint32_t j = 0; j < l; ++j) {
+        pb.begin_row(0, 0, MODE_ZERO);
+        key_row(c, pb, +1, n + j, 0, 0);
+        pb.challenge_term(rot, -1, 2, 1, j);
+        pb.add(-1, 3, j);
+      }
+      break;
     default: return RZK_E_ARG;
   }
   return RZK_OK;
@@ -525,7 +549,7 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
 
 int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
   const bool needs_key = !(id == PG_POLYMUL || id == PG_CMUL || id == PG_RESPONSE || id == PG_SUM_XP ||
-                           id == PG_SUM_W2 || id == PG_REL_ROT);
+                           id == PG_SUM_W2 || id == PG_REL_ROT);   // (PG_SUM_D reads the key's classification)
   if (needs_key && !c->key_loaded) return fail(c, RZK_E_STATE, "commitment key not loaded");
   auto it = c->progs.find({id, var});
   if (it != c->progs.end()) {
@@ -1076,6 +1100,7 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
     if (g >= 1 && g <= (c->logn >= 11 ? 2 : RZK_GROUP_GM)) c->group_max = g;   // bounded by the compiled accumulators
   }
   if (const char* e = std::getenv("RZK_SHIFT")) c->use_shift = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RZK_SUM_D")) c->sum_d = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("RZK_PRESET_IN_KERNEL")) c->preset_in_kernel = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_PAIRS")) c->use_pairs = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_UPT")) c->units_per_task = (uint32_t)std::atoi(e);
@@ -1579,13 +1604,42 @@ int rzk_linear_verify_batch_dev(rzk_ctx* c, const int64_t* z, const int64_t* zp,
 // =================================================================================================
 // SumProof
 // =================================================================================================
+namespace {
+// sum_i g_i (.) (a2.v_i) - a2.v'  (sum.rs:154-160, 301-308) evaluated as a2.(sum_i g_i (.) v_i - v'): V matrix-vector
+// products (each with its inverse transforms) become one, for (columns of a2) instead of l rows of V vector x vector
+// terms.  Chosen by transform count (forward + inverse, per proof): pays when V is large and a2 has few columns beyond
+// its identity block — the reference's key shape; a dense a2 with k > l columns keeps the row-wise form.
+bool sum_uses_d(const rzk_ctx* c, uint32_t V) {
+  if (c->small) return false;
+  if (c->sum_d >= 0) return c->sum_d != 0;
+  const uint32_t n = c->n, k = c->k, l = c->l;
+  uint32_t cols = 0, fwd = 0, key_terms = 0;   // columns a2 uses; of those with general entries; general entries in all
+  for (uint32_t col = 0; col < k; ++col) {
+    bool used = false, general = false;
+    for (uint32_t j = 0; j < l; ++j) {
+      const uint8_t kc = c->key_class[(n + j) * k + col];
+      used = used || kc != KC_ZERO;
+      general = general || kc == KC_GENERAL;
+      key_terms += kc == KC_GENERAL;
+    }
+    cols += used;
+    fwd += general;
+  }
+  const uint64_t matvec2 = 2ull * (fwd + l), matvec3 = 3ull * (fwd + l);           // a2.v at two / three primes
+  const uint64_t rowwise = (uint64_t)V * matvec2 + (uint64_t)l * (6ull * V + 3) + 3ull * key_terms;
+  const uint64_t by_d = (uint64_t)cols * (6ull * V + 3) + matvec3;
+  return by_d < rowwise && (uint64_t)cols * V <= (uint64_t)kMaxTerms && cols <= (uint32_t)kMaxRows;
+}
+}  // namespace
+
 int rzk_sum_commit_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* gs, const int64_t* xs, const int64_t* rs,
                              const int64_t* rp, const int64_t* ys, const int64_t* yp, int64_t* cs, int64_t* cpm,
                              int64_t* ts, int64_t* tp, int64_t* u, uint8_t* ok, size_t B) {
   if (c && B == 0) return RZK_OK;   // empty batch: nothing to do (pointers may be NULL)
   if (!c || V == 0 || !gs || !xs || !rs || !rp || !ys || !yp || !cs || !cpm || !ts || !tp || !u) return RZK_E_ARG;
   const uint32_t n = c->n, k = c->k, l = c->l;
-  int rc = arena_reserve(c, c->ws, polys(c, B * l + B * V * l));
+  const size_t wpolys = (size_t)B * V * l > (size_t)B * k ? (size_t)B * V * l : (size_t)B * k;   // w[B*V][l], or D[B][k]
+  int rc = arena_reserve(c, c->ws, polys(c, B * l + wpolys));
   if (rc != RZK_OK) return rc;
   int64_t* xp = (int64_t*)c->ws.p;
   int64_t* w = xp + B * l * c->N;
@@ -1618,6 +1672,12 @@ int rzk_sum_commit_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* gs, const in
     if (rc != RZK_OK) return rc;
   }
   // sum.rs:154-160: u = sum_i (a2.y_i)(.)g_i - a2.yp
+  if (sum_uses_d(c, V)) {   // = a2.(sum_i g_i(.)y_i - yp): D (k polynomials per proof, the columns a2 uses) lives where w would
+    int64_t* D = w;
+    rc = run_program(c, PG_SUM_D, V, {{ys, V * k, 0}, {gs, V, 0}, {yp, k, 0}, {D, k, 0}}, ok, 1, B);
+    if (rc != RZK_OK) return rc;
+    return run_program(c, PG_MATVEC, RZK_KEY_A2 * 2, {{D, k, 0}, {nullptr, l, 0}, {u, l, 0}}, ok, 1, B);
+  }
   rc = run_program(c, PG_MATVEC, RZK_KEY_A2 * 2, {{ys, k, 0}, {nullptr, l, 0}, {w, l, 0}}, nullptr, 1, B * V);
   if (rc != RZK_OK) return rc;
   return run_program(c, PG_SUM_U, V, {{w, V * l, 0}, {gs, V, 0}, {yp, k, 0}, {u, l, 0}}, ok, 1, B);
@@ -1642,10 +1702,12 @@ int rzk_sum_verify_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* zs, const in
   if (!c || V == 0 || !zs || !zp || !cs || !cpm || !gs || !ts || !tp || !u || !d || !accept) return RZK_E_ARG;
   if (c->n != c->l) return fail(c, RZK_E_ARG, "c1_c2 split needs n == l (reference panics in Mat::add)");
   const uint32_t n = c->n, k = c->k, l = c->l;
-  int rc = arena_reserve(c, c->ws, polys(c, B * V * l + B * l + B * V * n));
+  const bool by_d = sum_uses_d(c, V);
+  const size_t w1polys = by_d && (size_t)B * k > (size_t)B * V * l ? (size_t)B * k : (size_t)B * V * l;   // w1[B*V][l], or D[B][k]
+  int rc = arena_reserve(c, c->ws, polys(c, w1polys + B * l + B * V * n));
   if (rc != RZK_OK) return rc;
   int64_t* w1 = (int64_t*)c->ws.p;
-  int64_t* w2 = w1 + B * V * l * c->N;
+  int64_t* w2 = w1 + w1polys * c->N;
   int64_t* w0 = w2 + B * l * c->N;   // a1.z of the relation checks (n >= 2 only)
   const std::vector<OpSpec> rel_s = {{zs, k, 0}, {ts, n, 0}, {cs, n + l, 0}, {d, 1, 1}};
   const std::vector<OpSpec> rel_p = {{zp, k, 0}, {tp, n, 0}, {cpm, n + l, 0}, {d, 1, 0}};
@@ -1656,6 +1718,14 @@ int rzk_sum_verify_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* zs, const in
   rc = run_a1_relation(c, rel_p, w0, accept, 1, B, B, false);
   if (rc != RZK_OK) return rc;
   // sum.rs:301-319
+  if (by_d) {   // lhs = a2.(sum_i g_i(.)z_i - zp): D in w1's place, then one relation row per row of a2
+    int64_t* D = w1;
+    rc = run_program(c, PG_SUM_D, V, {{zs, V * k, 0}, {gs, V, 0}, {zp, k, 0}, {D, k, 0}}, accept, 1, B, 0, false);
+    if (rc != RZK_OK) return rc;
+    rc = run_program(c, PG_SUM_W2, V, {{cs, V * (n + l), 0}, {gs, V, 0}, {cpm, n + l, 0}, {w2, l, 0}}, accept, 1, B, 0, false);
+    if (rc != RZK_OK) return rc;
+    return run_program(c, PG_SUM_V4, 0, {{D, k, 0}, {w2, l, 0}, {d, 1, 0}, {u, l, 0}}, accept, 1, B, 0, false);
+  }
   rc = run_program(c, PG_MATVEC, RZK_KEY_A2 * 2, {{zs, k, 0}, {nullptr, l, 0}, {w1, l, 0}}, accept, V, B * V, 0, false);
   if (rc != RZK_OK) return rc;
   rc = run_program(c, PG_SUM_W2, V, {{cs, V * (n + l), 0}, {gs, V, 0}, {cpm, n + l, 0}, {w2, l, 0}}, accept, 1, B, 0, false);

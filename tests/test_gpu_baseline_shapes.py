@@ -236,6 +236,12 @@ def test_config5_shape_vs_oracle(torch_mod):
     dict(N=2048, shape=(1, 3, 1), V=2, env={"RZK_SHIFT": 0}),
     dict(N=2048, shape=(2, 5, 2), V=2, env={"RZK_SHIFT": 0}),
     dict(N=2048, shape=(2, 5, 2), V=2, env={"RZK_VEC_ROWS": 0, "RZK_BLOCK_MIN_LOGN": 12}),   # unit_kernel<11, true, true, PairTeam>
+    # Sum proof's u and final relation through a2.(sum_i g_i v_i - v') (the default where it saves transforms: large V,
+    # the reference's key shape) and row by row, each forced where the cost model would choose the other
+    dict(N=512, shape=(1, 3, 1), V=3, env={"RZK_SUM_D": 1}),
+    dict(N=1024, shape=(2, 5, 2), V=2, env={"RZK_SUM_D": 1}),
+    dict(N=2048, shape=(2, 5, 2), V=3, env={"RZK_SUM_D": 1}),
+    dict(N=1024, shape=(4, 9, 4), V=8, env={"RZK_SUM_D": 0}),
 ])
 def test_forced_kernel_paths_vs_oracle(torch_mod, cfg):
     N, (n, k, l), V = cfg["N"], cfg["shape"], cfg["V"]

@@ -31,6 +31,8 @@ KNOBS = [
     {"RZK_UNIT_IO": 1},     # key-product programs through unit_io_kernel at every N (default: N = 512 only)
     {"RZK_UNIT_IO": 0},     # ... and through unit_kernel at N = 512
     {"RZK_UPT": 64, "RZK_PRESET_IN_KERNEL": 0},   # one team per entry, verdict flags preset by a fill launch (default: by the team)
+    {"RZK_SUM_D": 1},       # Sum proof: a2.(sum_i g_i v_i - v') whatever the cost model says
+    {"RZK_SUM_D": 0},       # ... and sum_i g_i (a2.v_i) - a2.v' row by row
 ]
 
 

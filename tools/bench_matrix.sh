@@ -2,7 +2,7 @@
 # Quick matrix of the BASELINE configurations (GPU box): kernels only, no CPU baseline, no secondary regions.
 #   tools/bench_matrix.sh <tag> [chunks...]   ->  gpurun_out/<tag>_matrix.jsonl + a one-line summary per configuration
 tag=${1:-m}; shift
-chunks=${@:-256}
+chunks=${@:-512}
 cd "$(dirname "$0")/.."
 out=gpurun_out/${tag}_matrix.jsonl
 : > $out

@@ -67,6 +67,7 @@ struct DevProg {
   uint32_t nslots = 0;
   uint32_t np_store = 0;
   uint32_t ngroups = 0;   // > 0: row groups (row_group_kernel)
+  bool has_dkey = false;  // products with prepared multiplier images (TERM_DKEY): row_kernel only
   bool shift = false;     // every product has the sparse challenge as multiplier: shift_row_kernel
   bool has_shift = false; // some rows end with challenge products evaluated by rotations inside row_kernel
   bool two_bit = false;   // two-bit verdict flags (CHECK2 marks)
@@ -110,6 +111,11 @@ struct rzk_ctx {
   bool use_pairs = true;               // unit_kernel: pair rows that share their last operand (RZK_PAIRS=0 turns it off, tuning)
   int group_max = 1;                   // rows per group of row_group_kernel (group_max_for; RZK_GROUP_MAX overrides, tuning)
   bool use_shift = true;               // challenge products as signed rotations (shift_row_kernel) instead of transforms
+  bool use_dkey = true;                // the scalar multipliers g_i of Linear / Sum transformed once per proof and call (TERM_DKEY; RZK_DKEY=0: every row transforms them itself)
+  Arena ws_dkey;                       // their images + norms
+  const uint32_t* dkey_img = nullptr;  // images of the call in progress (set by prepare_dkey, cleared by the entry point)
+  const double* dkey_l2 = nullptr;
+  uint32_t dkey_n = 0;
   int sum_d = -1;                      // Sum proof: a2.(sum_i g_i v_i - v') instead of sum_i g_i (a2.v_i) - a2.v' (-1 = by cost, RZK_SUM_D=0|1 forces)
   bool preset_in_kernel = true;        // verdict flags initialised by the unit kernels themselves where one team owns an entry (RZK_PRESET_IN_KERNEL=0: always a fill launch)
   bool small = false;                  // N < 512: schoolbook kernels (rzk_kernels.hip, "small ring degrees")
@@ -224,6 +230,24 @@ struct PB {
     t.b_off = (uint16_t)voff;
     p.rows[cur].nterms++;
   }
+  // sign * (image `idx` of the entry's own multipliers) (.) (bop,boff): Operands::dkey_img, row_kernel only
+  void dkey_term(int sign, uint32_t idx, uint8_t bop, uint32_t boff) {
+    if (cur < 0 || p.nterms >= (uint32_t)kMaxTerms || idx > 0xffff || boff > 0xffff || p.rows[cur].nshift) { overflow = true; return; }
+    Term& t = p.terms[p.nterms++];
+    t.kind = TERM_DKEY;
+    t.sign = (int8_t)sign;
+    t.a_op = 0;
+    t.a_off = (uint16_t)idx;
+    t.b_op = bop;
+    t.b_off = (uint16_t)boff;
+    p.rows[cur].nterms++;
+  }
+  // a product with one of the entry's scalar multipliers (operand gop, index idx): its image when the call prepared
+  // them (dk), a vector x vector term otherwise
+  void scalar_term(bool dk, int sign, uint8_t gop, uint32_t idx, uint8_t bop, uint32_t boff) {
+    if (dk) dkey_term(sign, idx, bop, boff);
+    else vec_term(sign, bop, boff, gop, idx);
+  }
   void vec_term(int sign, uint8_t aop, uint32_t aoff, uint8_t bop, uint32_t boff) {
     if (cur < 0 || p.nterms >= (uint32_t)kMaxTerms || aoff > 0xffff || boff > 0xffff || p.rows[cur].nshift) { overflow = true; return; }
     Term& t = p.terms[p.nterms++];
@@ -311,9 +335,14 @@ void key_row(rzk_ctx* c, PB& pb, int sign, uint32_t krow, uint8_t vop, uint32_t 
 // (one or two waves per SIMD) and measured slower than the transform path (round 2).
 bool shift_ok(const rzk_ctx* c) { return c->use_shift && !c->small && (c->logn <= 10 || c->pair_poly); }
 
-int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
+// bit of a program variant: products with the entry's scalar multipliers (g, g_i) take their prepared images (TERM_DKEY)
+constexpr uint32_t kDkeyVar = 0x10000u;
+
+int build_program(rzk_ctx* c, int id, uint32_t var_in, PB& pb) {
   const uint32_t n = c->n, k = c->k, l = c->l;
   const bool rot = shift_ok(c);   // challenge products inside mixed rows as rotations
+  const bool dk = (var_in & kDkeyVar) != 0;
+  const uint32_t var = var_in & ~kDkeyVar;
   switch (id) {
     case PG_MATVEC: {   // ops: 0 = v[k], 1 = addend[rows], 2 = out[rows]
       const uint32_t which = var >> 1;
@@ -334,7 +363,7 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
     case PG_CMUL:      // ops: 0 = m[rows], 1 = p, 2 = out[rows]   (mat.rs:168-178)
       for (uint32_t i = 0; i < var; ++i) {
         pb.begin_row(2, i, MODE_STORE);
-        pb.vec_term(+1, 0, i, 1, 0);
+        pb.scalar_term(dk, +1, 1, 0, 0, i);
       }
       break;
     case PG_OPEN_COMMIT:   // ops: 0 = x[l], 1 = r[k], 2 = y[k], 3 = c[n+l], 4 = t[n]
@@ -449,7 +478,7 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
     case PG_LIN_U:   // ops: 0 = a2y[l], 1 = g, 2 = yp[k], 3 = u[l] : u = a2y(.)g - a2.yp (linear.rs:124-129)
       for (uint32_t i = 0; i < l; ++i) {
         pb.begin_row(3, i, MODE_STORE);
-        pb.vec_term(+1, 0, i, 1, 0);
+        pb.scalar_term(dk, +1, 1, 0, 0, i);
         key_row(c, pb, -1, n + i, 2, 0);
       }
       break;
@@ -474,7 +503,7 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
       }
       for (uint32_t i = 0; i < l; ++i) {       // c2(.)g - c2p (linear.rs:243-246); c2 = last n rows of c
         pb.begin_row(9, i, MODE_STORE);
-        pb.vec_term(+1, 4, l + i, 7, 0);
+        pb.scalar_term(dk, +1, 7, 0, 4, l + i);
         pb.add(-1, 5, l + i);
       }
       if (var & 1) {   // fused check_verify_constraint(z), (zp)  (linear.rs:218-223)
@@ -486,7 +515,7 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
       // w1(.)g - a2.zp - w2(.)d - u == 0   (linear.rs:237-249)
       for (uint32_t i = 0; i < l; ++i) {
         pb.begin_row(0, 0, MODE_ZERO);
-        pb.vec_term(+1, 0, i, 2, 0);
+        pb.scalar_term(dk, +1, 2, 0, 0, i);
         key_row(c, pb, -1, n + i, 4, 0);
         pb.challenge_term(rot, -1, 3, 1, i);
         pb.add(-1, 5, i);
@@ -495,27 +524,27 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
     case PG_SUM_XP:   // ops: 0 = xs[V*l], 1 = gs[V], 2 = xp[l] : xp = sum_i x_i (.) g_i (sum.rs:107-115)
       for (uint32_t j = 0; j < l; ++j) {
         pb.begin_row(2, j, MODE_STORE);
-        for (uint32_t i = 0; i < var; ++i) pb.vec_term(+1, 0, i * l + j, 1, i);
+        for (uint32_t i = 0; i < var; ++i) pb.scalar_term(dk, +1, 1, i, 0, i * l + j);
       }
       break;
     case PG_SUM_U:    // ops: 0 = w[V*l] (a2.y_i), 1 = gs[V], 2 = yp[k], 3 = u[l]   (sum.rs:154-160)
       for (uint32_t j = 0; j < l; ++j) {
         pb.begin_row(3, j, MODE_STORE);
-        for (uint32_t i = 0; i < var; ++i) pb.vec_term(+1, 0, i * l + j, 1, i);
+        for (uint32_t i = 0; i < var; ++i) pb.scalar_term(dk, +1, 1, i, 0, i * l + j);
         key_row(c, pb, -1, n + j, 2, 0);
       }
       break;
     case PG_SUM_W2:   // ops: 0 = cs[V*(n+l)], 1 = gs[V], 2 = cp[n+l], 3 = w2[l] : sum_i c2_i(.)g_i - c2p (sum.rs:309-316)
       for (uint32_t j = 0; j < l; ++j) {
         pb.begin_row(3, j, MODE_STORE);
-        for (uint32_t i = 0; i < var; ++i) pb.vec_term(+1, 0, i * (n + l) + l + j, 1, i);
+        for (uint32_t i = 0; i < var; ++i) pb.scalar_term(dk, +1, 1, i, 0, i * (n + l) + l + j);
         pb.add(-1, 2, l + j);
       }
       break;
     case PG_SUM_V3:   // ops: 0 = w1[V*l] (a2.z_i), 1 = gs[V], 2 = zp[k], 3 = w2[l], 4 = d, 5 = u[l]   (sum.rs:301-319)
       for (uint32_t j = 0; j < l; ++j) {
         pb.begin_row(0, 0, MODE_ZERO);
-        for (uint32_t i = 0; i < var; ++i) pb.vec_term(+1, 0, i * l + j, 1, i);
+        for (uint32_t i = 0; i < var; ++i) pb.scalar_term(dk, +1, 1, i, 0, i * l + j);
         key_row(c, pb, -1, n + j, 2, 0);
         pb.challenge_term(rot, -1, 4, 3, j);
         pb.add(-1, 5, j);
@@ -529,7 +558,7 @@ int build_program(rzk_ctx* c, int id, uint32_t var, PB& pb) {
         for (uint32_t j = 0; j < l; ++j) used = used || c->key_class[(n + j) * k + col] != KC_ZERO;
         if (!used) continue;
         pb.begin_row(3, col, MODE_STORE);
-        for (uint32_t i = 0; i < var; ++i) pb.vec_term(+1, 0, i * k + col, 1, i);
+        for (uint32_t i = 0; i < var; ++i) pb.scalar_term(dk, +1, 1, i, 0, i * k + col);
         pb.add(-1, 2, col);
       }
       break;
@@ -574,12 +603,13 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
     dp.shift = all;
   }
   for (uint32_t r = 0; r < pb.p.nrows; ++r) dp.has_shift = dp.has_shift || pb.p.rows[r].nshift > 0;
+  for (uint32_t t = 0; t < pb.p.nterms; ++t) dp.has_dkey = dp.has_dkey || (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_DKEY;
   dp.two_bit = pb.two_bit;
   // Row blocks: key-only programs whose rows share operands; consecutive rows are packed into blocks of at
   // most kBlockMaxRows rows and kBlockMaxSlots distinct operands.  Used when every operand is needed by at
   // least two terms on average (otherwise nothing is shared and the plain row kernel is as good).
   if (!c->small && c->logn >= 10 && c->logn >= c->block_min_logn && !dp.shift && !dp.has_shift && !dp.two_bit &&
-      pb.p.nterms > 0) {
+      !dp.has_dkey && pb.p.nterms > 0) {
     bool key_only = true;
     for (uint32_t t = 0; t < pb.p.nterms; ++t) key_only = key_only && (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_KEY;
     std::vector<BlockPlan> planv(1);
@@ -639,7 +669,7 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
       }
     }
   }
-  if (!c->small && c->use_groups && !dp.shift && !dp.two_bit && !dp.nblocks) {
+  if (!c->small && c->use_groups && !dp.shift && !dp.two_bit && !dp.nblocks && !dp.has_dkey) {
     bool key_only = pb.p.nterms > 0;
     for (uint32_t t = 0; t < pb.p.nterms; ++t) key_only = key_only && (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_KEY;
     if (key_only) {
@@ -736,7 +766,7 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
   // distinct operands of the product terms ("slots"); when rows share them often enough, transform each
   // once per proof (shared-operand path) instead of once per row
   if (!c->small && c->slot_share_min > 0 && pb.p.nterms > 0 && dp.ngroups == 0 && !dp.shift && !dp.has_shift &&
-      !dp.two_bit && !dp.nblocks) {
+      !dp.two_bit && !dp.nblocks && !dp.has_dkey) {
     std::vector<SlotTable> stv(1);
     SlotTable& st = stv[0];
     std::memset(&st, 0, sizeof(st));
@@ -830,7 +860,8 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
   // fills the chip's wave slots; one unit per task below that
   uint32_t upt = batch >= (uint64_t)c->num_cus * 16 ? dp.nunits : 1;
   if (c->units_per_task) upt = c->units_per_task;   // RZK_UPT (tuning)
-  const bool unit_path = !c->small && !dp.shift && !dp.nblocks && !dp.ngroups && !dp.d_slots && !(dp.has_vec && c->vec_rows);
+  const bool row_path = dp.has_dkey || (dp.has_vec && c->vec_rows);   // row_kernel: vector x vector products, prepared multiplier images
+  const bool unit_path = !c->small && !dp.shift && !dp.nblocks && !dp.ngroups && !dp.d_slots && !row_path;
   const bool preset_in_kernel = preset_value && flags && c->preset_in_kernel && unit_path && upt >= dp.nunits && dp.nunits > 0 &&
                                 (group ? group : 1) == 1 && nflags == batch;
   if (preset_value && flags && !preset_in_kernel) {
@@ -849,6 +880,12 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
   ops.bad = sticky ? c->d_bad : nullptr;
   ops.trusted = c->trusted ? 1u : 0u;
   ops.preset = preset_in_kernel ? preset_value : 0u;
+  if (dp.has_dkey) {
+    if (!c->dkey_img || c->small) return fail(c, RZK_E_STATE, "multiplier images not prepared");
+    ops.dkey_img = c->dkey_img;
+    ops.dkey_l2 = c->dkey_l2;
+    ops.dkey_n = c->dkey_n;
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (c->prof) {
     if (c->prof_used == c->prof_events.size()) {
@@ -871,7 +908,7 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
     else if (dp.nblocks) pi.kernel = "row_block_kernel<" + L + (pairs ? ", BlockPairTeam>" : ">");
     else if (dp.ngroups) pi.kernel = "row_group_kernel<" + L + ", " + std::to_string(c->logn >= 11 ? 2 : RZK_GROUP_GM) + ">";
     else if (dp.d_slots) pi.kernel = "fwd_slots_kernel<" + L + "> + row_slots_kernel<" + L + ">";
-    else if (dp.has_vec && c->vec_rows)
+    else if (row_path)
       pi.kernel = "row_kernel<" + L + ", " + (dp.has_shift ? "true" : "false") + (pairs ? ", PairTeam>" : ">");
     else if (!dp.has_vec && c->unit_io && !(c->logn == 11 && dp.has_shift))
       pi.kernel = "unit_io_kernel<" + L + ", " + (dp.has_shift ? "true" : "false") + (pairs ? ", PairTeam>" : ">");
@@ -926,7 +963,7 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
                                      flags ? flags + b0 / grp : nullptr, nb, dp.np_store);
     }
   } else {
-    if (dp.has_vec && c->vec_rows) {
+    if (row_path) {
       lrc = launch_rows((int)c->logn, cfg_of(c), dp.d, dp.nrows, dp.has_shift, ops, c->d_key_ntt, c->d_key_l2, c->dT, c->d_tw,
                         c->d_row_scratch, flags, batch);
     } else {
@@ -977,6 +1014,50 @@ int run_program_checked(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSp
   const uint8_t all_ok = dp.two_bit ? 3 : 1;
   return run_program(c, id, var | 1, specs, flags, group, batch, lim, sticky, preset ? all_ok : (uint8_t)0, nflags);
 }
+
+// The scalar multipliers of a Linear / Sum call (g: one per proof; g_i: V per proof) transformed once into the form of the
+// resident key, for the TERM_DKEY terms of the call's row programs (variant bit kDkeyVar).  flags / sticky as in
+// run_program: a non-canonical coefficient clears the proof's verdict and / or raises the sticky word.  Leaves
+// c->dkey_img NULL when the path is off (RZK_DKEY=0, small rings): the callers then ask for the plain variants.
+int prepare_dkey(rzk_ctx* c, const int64_t* g, uint64_t entries, uint32_t per_entry, uint8_t* flags, bool sticky) {
+  c->dkey_img = nullptr;
+  c->dkey_l2 = nullptr;
+  c->dkey_n = 0;
+  if (!c->use_dkey || c->small || entries == 0) return RZK_OK;
+  const uint64_t count = entries * per_entry;
+  const size_t img_bytes = ((size_t)count * kKeyImages * c->N * sizeof(uint32_t) + 255) & ~(size_t)255;
+  int rc = arena_reserve(c, c->ws_dkey, img_bytes + (size_t)count * sizeof(double));
+  if (rc != RZK_OK) return rc;
+  uint32_t* img = (uint32_t*)c->ws_dkey.p;
+  double* l2 = (double*)((char*)c->ws_dkey.p + img_bytes);
+  hipEvent_t e1 = nullptr;
+  if (c->prof) {
+    if (c->prof_used == c->prof_events.size()) {
+      hipEvent_t a, b;
+      HIPCHK(c, hipEventCreateWithFlags(&a, hipEventDisableSystemFence));
+      HIPCHK(c, hipEventCreateWithFlags(&b, hipEventDisableSystemFence));
+      c->prof_events.push_back({a, b});
+    }
+    hipEvent_t e0 = c->prof_events[c->prof_used].first;
+    e1 = c->prof_events[c->prof_used].second;
+    if (c->prof_info.size() <= c->prof_used) c->prof_info.resize(c->prof_used + 1);
+    rzk_ctx::ProfInfo& pi = c->prof_info[c->prof_used];
+    pi.kernel = "dkey_transform_kernel<" + std::to_string(c->logn) + ">";
+    pi.bytes = count * 8ull * c->N;   // the multipliers it reads; the images are derived data
+    c->prof_used++;
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+  }
+  rc = check_launch(c, launch_dkey_transform((int)c->logn, cfg_of(c), g, count, per_entry, img, l2, c->dT, c->d_tw, flags,
+                                             sticky ? c->d_bad : nullptr, false, c->trusted), "multiplier images");
+  if (rc != RZK_OK) return rc;
+  if (e1) HIPCHK(c, hipEventRecord(e1, c->stream));
+  c->dkey_img = img;
+  c->dkey_l2 = l2;
+  c->dkey_n = per_entry;
+  return RZK_OK;
+}
+// variant bit for programs that multiply by the call's scalar multipliers
+uint32_t dkv(const rzk_ctx* c) { return c->dkey_img ? kDkeyVar : 0u; }
 
 bool can_fuse(rzk_ctx* c, int id, uint32_t var, uint64_t bound) {
   DevProg dp;
@@ -1101,6 +1182,7 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
   }
   if (const char* e = std::getenv("RZK_SHIFT")) c->use_shift = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_SUM_D")) c->sum_d = std::atoi(e) != 0 ? 1 : 0;
+  if (const char* e = std::getenv("RZK_DKEY")) c->use_dkey = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_PRESET_IN_KERNEL")) c->preset_in_kernel = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_PAIRS")) c->use_pairs = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_UPT")) c->units_per_task = (uint32_t)std::atoi(e);
@@ -1152,6 +1234,7 @@ void rzk_ctx_destroy(rzk_ctx* c) {
   if (c->d_key_l2) (void)hipFree(c->d_key_l2);
   if (c->ws.p) (void)hipFree(c->ws.p);
   if (c->ws_slots.p) (void)hipFree(c->ws_slots.p);
+  if (c->ws_dkey.p) (void)hipFree(c->ws_dkey.p);
   if (c->stage.p) (void)hipFree(c->stage.p);
   if (c->dT) (void)hipFree(c->dT);
   if (c->d_tw) (void)hipFree(c->d_tw);
@@ -1646,7 +1729,14 @@ int rzk_sum_commit_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* gs, const in
   // sum.rs:107-115: xp = sum_i x_i (.) g_i
   // (XP runs before ok is preset: a non-canonical x_i / g_i is reported through the sticky word, and again by the
   //  later rows that load the same polynomials with the flags in place)
-  rc = run_program(c, PG_SUM_XP, V, {{xs, V * l, 0}, {gs, V, 0}, {xp, l, 0}}, nullptr, 1, B);
+  // the V multipliers g_i of every proof, transformed once for all the rows that multiply by them (XP, D / U)
+  rc = prepare_dkey(c, gs, B, V, nullptr, true);
+  if (rc != RZK_OK) return rc;
+  struct DkeyScope {   // the images belong to this call
+    rzk_ctx* c;
+    ~DkeyScope() { c->dkey_img = nullptr; c->dkey_l2 = nullptr; c->dkey_n = 0; }
+  } dkey_scope{c};
+  rc = run_program(c, PG_SUM_XP, V | dkv(c), {{xs, V * l, 0}, {gs, V, 0}, {xp, l, 0}}, nullptr, 1, B);
   if (rc != RZK_OK) return rc;
   // sum.rs:116 and 151: cp = commit(xp; rp), tp = a1.yp
   const std::vector<OpSpec> cp_specs = {{xp, l, 0}, {rp, k, 0}, {yp, k, 0}, {cpm, n + l, 0}, {tp, n, 0}};
@@ -1674,13 +1764,13 @@ int rzk_sum_commit_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* gs, const in
   // sum.rs:154-160: u = sum_i (a2.y_i)(.)g_i - a2.yp
   if (sum_uses_d(c, V)) {   // = a2.(sum_i g_i(.)y_i - yp): D (k polynomials per proof, the columns a2 uses) lives where w would
     int64_t* D = w;
-    rc = run_program(c, PG_SUM_D, V, {{ys, V * k, 0}, {gs, V, 0}, {yp, k, 0}, {D, k, 0}}, ok, 1, B);
+    rc = run_program(c, PG_SUM_D, V | dkv(c), {{ys, V * k, 0}, {gs, V, 0}, {yp, k, 0}, {D, k, 0}}, ok, 1, B);
     if (rc != RZK_OK) return rc;
     return run_program(c, PG_MATVEC, RZK_KEY_A2 * 2, {{D, k, 0}, {nullptr, l, 0}, {u, l, 0}}, ok, 1, B);
   }
   rc = run_program(c, PG_MATVEC, RZK_KEY_A2 * 2, {{ys, k, 0}, {nullptr, l, 0}, {w, l, 0}}, nullptr, 1, B * V);
   if (rc != RZK_OK) return rc;
-  return run_program(c, PG_SUM_U, V, {{w, V * l, 0}, {gs, V, 0}, {yp, k, 0}, {u, l, 0}}, ok, 1, B);
+  return run_program(c, PG_SUM_U, V | dkv(c), {{w, V * l, 0}, {gs, V, 0}, {yp, k, 0}, {u, l, 0}}, ok, 1, B);
 }
 
 int rzk_sum_response_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* ys, const int64_t* yp, const int64_t* rs,
@@ -1717,20 +1807,27 @@ int rzk_sum_verify_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* zs, const in
   if (rc != RZK_OK) return rc;
   rc = run_a1_relation(c, rel_p, w0, accept, 1, B, B, false);
   if (rc != RZK_OK) return rc;
-  // sum.rs:301-319
+  // sum.rs:301-319.  The multipliers' images are prepared AFTER the relation rows above have initialised accept: a
+  // non-canonical g_i must clear the proof's verdict, and nothing presets the flags again from here on.
+  rc = prepare_dkey(c, gs, B, V, accept, false);
+  if (rc != RZK_OK) return rc;
+  struct DkeyScope {
+    rzk_ctx* c;
+    ~DkeyScope() { c->dkey_img = nullptr; c->dkey_l2 = nullptr; c->dkey_n = 0; }
+  } dkey_scope{c};
   if (by_d) {   // lhs = a2.(sum_i g_i(.)z_i - zp): D in w1's place, then one relation row per row of a2
     int64_t* D = w1;
-    rc = run_program(c, PG_SUM_D, V, {{zs, V * k, 0}, {gs, V, 0}, {zp, k, 0}, {D, k, 0}}, accept, 1, B, 0, false);
+    rc = run_program(c, PG_SUM_D, V | dkv(c), {{zs, V * k, 0}, {gs, V, 0}, {zp, k, 0}, {D, k, 0}}, accept, 1, B, 0, false);
     if (rc != RZK_OK) return rc;
-    rc = run_program(c, PG_SUM_W2, V, {{cs, V * (n + l), 0}, {gs, V, 0}, {cpm, n + l, 0}, {w2, l, 0}}, accept, 1, B, 0, false);
+    rc = run_program(c, PG_SUM_W2, V | dkv(c), {{cs, V * (n + l), 0}, {gs, V, 0}, {cpm, n + l, 0}, {w2, l, 0}}, accept, 1, B, 0, false);
     if (rc != RZK_OK) return rc;
     return run_program(c, PG_SUM_V4, 0, {{D, k, 0}, {w2, l, 0}, {d, 1, 0}, {u, l, 0}}, accept, 1, B, 0, false);
   }
   rc = run_program(c, PG_MATVEC, RZK_KEY_A2 * 2, {{zs, k, 0}, {nullptr, l, 0}, {w1, l, 0}}, accept, V, B * V, 0, false);
   if (rc != RZK_OK) return rc;
-  rc = run_program(c, PG_SUM_W2, V, {{cs, V * (n + l), 0}, {gs, V, 0}, {cpm, n + l, 0}, {w2, l, 0}}, accept, 1, B, 0, false);
+  rc = run_program(c, PG_SUM_W2, V | dkv(c), {{cs, V * (n + l), 0}, {gs, V, 0}, {cpm, n + l, 0}, {w2, l, 0}}, accept, 1, B, 0, false);
   if (rc != RZK_OK) return rc;
-  return run_program(c, PG_SUM_V3, V, {{w1, V * l, 0}, {gs, V, 0}, {zp, k, 0}, {w2, l, 0}, {d, 1, 0}, {u, l, 0}}, accept,
+  return run_program(c, PG_SUM_V3, V | dkv(c), {{w1, V * l, 0}, {gs, V, 0}, {zp, k, 0}, {w2, l, 0}, {d, 1, 0}, {u, l, 0}}, accept,
                      1, B, 0, false);
 }
 

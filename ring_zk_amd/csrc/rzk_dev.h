@@ -51,7 +51,7 @@ constexpr int kMaxAdds = 128;
 // TERM_SHIFT: (a_op,a_off) (*) (b_op,b_off) with a sparse `a` (the challenge d), evaluated as signed negacyclic
 // rotations (ShiftGeo, rzk_core.h) instead of transforms.  A row keeps its shift terms behind its transform
 // terms: terms[term0 .. term0+nterms) are KEY / VEC, terms[term0+nterms .. +nshift) are SHIFT.
-enum : uint8_t { TERM_KEY = 0, TERM_VEC = 1, TERM_SHIFT = 2, TERM_KIND_MASK = 0x3f };
+enum : uint8_t { TERM_KEY = 0, TERM_VEC = 1, TERM_SHIFT = 2, TERM_DKEY = 3, TERM_KIND_MASK = 0x3f };
 enum : uint8_t { MODE_STORE = 0, MODE_ZERO = 1 };
 // Fused norm predicate (Params::check_*_constraint, src/params.rs:102-118): a term (its b operand) or an
 // addition marked with CHECK also tests sum c^2 < Operands::norm_limit for the polynomial it loads and
@@ -66,7 +66,8 @@ constexpr uint8_t ADD_CHECK2 = 0x40;
 constexpr uint8_t ADD_OP_MASK = 0x3f;
 
 struct alignas(8) Term {
-  uint8_t kind;     // TERM_KEY: KEY[a_off] (*) operand(b_op, b_off);  TERM_VEC: (a_op,a_off) (*) (b_op,b_off)
+  uint8_t kind;     // TERM_KEY: KEY[a_off] (*) operand(b_op, b_off);  TERM_VEC: (a_op,a_off) (*) (b_op,b_off);
+                    // TERM_DKEY: image a_off of the batch entry's own multipliers (Operands::dkey_img) (*) operand(b_op, b_off)
   int8_t sign;      // +1 / -1
   uint8_t a_op, b_op;
   uint16_t a_off, b_off;
@@ -180,6 +181,13 @@ struct Operands {
   // one team evaluates ALL rows of a batch entry and flags are per entry (unit kernels with units_per_task = all, group 1);
   // otherwise the host presets the flags with a fill launch of its own (rzk_api.cpp, run_program)
   uint32_t preset;
+  // Per-entry multiplier images (TERM_DKEY, row_kernel only): the scalar polynomials g_i of the Linear / Sum proofs, which
+  // every vector x vector row of a proof multiplies by, transformed ONCE per proof and call (dkey_transform_kernel) into
+  // the form of the resident key: [entry][dkey_n][kKeyImages][N] residues x N^-1 x R, NTT-domain layout; dkey_l2 their
+  // 2-norms (upper bounds).  Entry = the proof index (b / group).
+  const uint32_t* dkey_img;
+  const double* dkey_l2;
+  uint32_t dkey_n, pad3;
 };
 
 // ---- launchers (defined in rzk_kernels.hip) --------------------------------------------------------------------
@@ -215,6 +223,10 @@ int launch_row_blocks(int logn, const LaunchCfg& cfg, const Program* d_prog, con
                       const uint32_t* d_tw, uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch);
 size_t block_scratch_words(int logn, int num_cus);
 // rows whose products all have a sparse multiplier (the challenge) as `a` operand: shift-add kernel, no transforms
+// images of `count` scalar multipliers (dkey_n per batch entry) for TERM_DKEY terms; flags / bad as in Operands
+int launch_dkey_transform(int logn, const LaunchCfg& cfg, const int64_t* g, uint64_t count, uint32_t dkey_n, uint32_t* img,
+                          double* l2, const DevTables* T, const uint32_t* d_tw, uint8_t* d_flags, uint32_t* d_bad, bool two_bit,
+                          bool trusted);
 int launch_shift_rows(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows, const Operands& ops,
                       const DevTables* d_T, uint8_t* d_flags, uint64_t batch);
 // rows per group; 1 = no grouping (at N = 2048 the accumulators cost too many registers: measured slower)

@@ -860,8 +860,11 @@ __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const 
       for (int c = 0; c < E; ++c) acc[c] = mac_sub(acc[c], x[c], xb[c], pc);
     }
   } else {
-    if (first) bound = bound_fma((float)key_l2[tm.a_off], nb, bound);
-    const uint4* __restrict__ kp = reinterpret_cast<const uint4*>(key_ntt + ((size_t)tm.a_off * kKeyImages + pi) * N);
+    // resident key entry, or (TERM_DKEY) one of the batch entry's own multiplier images — same form, same use
+    const bool dk = (tm.kind & TERM_KIND_MASK) == TERM_DKEY;
+    const size_t image = dk ? (size_t)bo * ops.dkey_n + tm.a_off : (size_t)tm.a_off;
+    if (first) bound = bound_fma((float)(dk ? ops.dkey_l2[image] : key_l2[image]), nb, bound);
+    const uint4* __restrict__ kp = reinterpret_cast<const uint4*>((dk ? ops.dkey_img : key_ntt) + (image * kKeyImages + pi) * N);
     if (tm.sign >= 0) {
 #pragma unroll
       for (int g = 0; g < E / 4; ++g) {
@@ -2608,6 +2611,68 @@ key_transform_kernel(const int64_t* __restrict__ key, uint32_t entries, uint32_t
   }
 }
 
+// Per-entry multiplier images (Operands::dkey_img): like key_transform_kernel, for polynomials that arrive with the batch
+// (the g_i of the Linear / Sum proofs).  One wavefront per polynomial: canonical test, 2-norm, then the three images.
+template <int LOGN>
+__global__ void __launch_bounds__(256)
+dkey_transform_kernel(const int64_t* __restrict__ g, uint64_t count, uint32_t dkey_n, uint32_t* __restrict__ img,
+                      double* __restrict__ l2, const DevTables* __restrict__ Tp, const uint32_t* __restrict__ tw_all,
+                      uint8_t* __restrict__ flags, uint32_t* __restrict__ bad_word, uint32_t two_bit, uint32_t trusted) {
+  using G = Geo<LOGN>;
+  constexpr int E = G::E;
+  constexpr int N = G::N;
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const DevTables& T = *Tp;
+  const int lane = threadIdx.x & 63;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  uint32_t* lds = smem + wave * G::LDS_WORDS;
+  for (uint64_t poly = (uint64_t)blockIdx.x * 4 + wave; poly < count; poly += (uint64_t)gridDim.x * 4) {
+    const int64_t* __restrict__ src = g + poly * N;
+    int32_t v[E];
+    if (trusted) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = (int32_t)src[G::j_p1(lane, e)];
+    } else {
+      uint32_t in_bad = 0, in_mx = 0;
+#pragma unroll
+      for (int e = 0; e < E; ++e) v[e] = canon_lo_mx(src[G::j_p1(lane, e)], T.crt.qhalf, in_bad, in_mx);
+      if (canon_fail(in_bad, in_mx, T.crt.qhalf) && lane == 0) {   // as input_fault: the proof's verdict (all bits) and the sticky word
+        const uint64_t entry = poly / dkey_n;
+        if (flags) {
+          if (two_bit) {
+            const uintptr_t a = reinterpret_cast<uintptr_t>(flags + entry);
+            __hip_atomic_fetch_and(reinterpret_cast<uint32_t*>(a & ~(uintptr_t)3), ~(0xffu << (8u * (uint32_t)(a & 3u))),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            flags[entry] = 0;
+          }
+        }
+        if (bad_word) *bad_word = 1u;
+      }
+    }
+    const float ss = wave_sum_f32(lane_sum_sq_f32<E>(v));
+    if (lane == 0) l2[poly] = (double)norm2_upper(ss) * (1.0 + 1e-6);   // upper bound of the 2-norm (read back as float)
+#pragma unroll 1
+    for (int pi = 0; pi < kKeyImages; ++pi) {
+      const PrimeConsts pc = T.pc[pi];
+      uint32_t x[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) x[e] = lift(v[e], pc);
+      wave_fwd<LOGN>(x, lane, lds, tw_all + (size_t)(2 * pi) * kTableLen, pc);
+      uint4* __restrict__ dst = reinterpret_cast<uint4*>(img + (poly * kKeyImages + pi) * N);
+#pragma unroll
+      for (int q4 = 0; q4 < E / 4; ++q4) {
+        uint4 o;
+        o.x = csub(mont_lazy(x[4 * q4 + 0], pc.ninv_r2, pc.p, pc.npinv), pc.p);
+        o.y = csub(mont_lazy(x[4 * q4 + 1], pc.ninv_r2, pc.p, pc.npinv), pc.p);
+        o.z = csub(mont_lazy(x[4 * q4 + 2], pc.ninv_r2, pc.p, pc.npinv), pc.p);
+        o.w = csub(mont_lazy(x[4 * q4 + 3], pc.ninv_r2, pc.p, pc.npinv), pc.p);
+        dst[q4 * 64 + lane] = o;
+      }
+    }
+  }
+}
+
 // =============================================================================================
 // Stand-alone batched transforms over one auxiliary prime (the "batched NTT" of the headline metric)
 // =============================================================================================
@@ -3253,6 +3318,28 @@ static int launch_shift_t(const LaunchCfg& cfg, const Program* d_prog, const Ope
                        T, d_flags, ntasks);
   RZK_LAUNCH_CHECK();
   return 0;
+}
+
+template <int LOGN>
+static int launch_dkey_t(const LaunchCfg& cfg, const int64_t* g, uint64_t count, uint32_t dkey_n, uint32_t* img, double* l2,
+                         const DevTables* T, const uint32_t* d_tw, uint8_t* d_flags, uint32_t* d_bad, bool two_bit, bool trusted) {
+  using G = Geo<LOGN>;
+  hipLaunchKernelGGL(dkey_transform_kernel<LOGN>, dim3(grid_for(count, cfg.num_cus)), dim3(256), 4 * G::LDS_WORDS * sizeof(uint32_t),
+                     (hipStream_t)cfg.stream, g, count, dkey_n, img, l2, T, d_tw, d_flags, d_bad, two_bit ? 1u : 0u,
+                     trusted ? 1u : 0u);
+  RZK_LAUNCH_CHECK();
+  return 0;
+}
+int launch_dkey_transform(int logn, const LaunchCfg& cfg, const int64_t* g, uint64_t count, uint32_t dkey_n, uint32_t* img,
+                          double* l2, const DevTables* T, const uint32_t* d_tw, uint8_t* d_flags, uint32_t* d_bad, bool two_bit,
+                          bool trusted) {
+  if (count == 0) return 0;
+  switch (logn) {
+    case 9: return launch_dkey_t<9>(cfg, g, count, dkey_n, img, l2, T, d_tw, d_flags, d_bad, two_bit, trusted);
+    case 10: return launch_dkey_t<10>(cfg, g, count, dkey_n, img, l2, T, d_tw, d_flags, d_bad, two_bit, trusted);
+    case 11: return launch_dkey_t<11>(cfg, g, count, dkey_n, img, l2, T, d_tw, d_flags, d_bad, two_bit, trusted);
+  }
+  return -1;
 }
 
 int launch_shift_rows(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows, const Operands& ops,

@@ -111,7 +111,8 @@ struct rzk_ctx {
   bool use_pairs = true;               // unit_kernel: pair rows that share their last operand (RZK_PAIRS=0 turns it off, tuning)
   int group_max = 1;                   // rows per group of row_group_kernel (group_max_for; RZK_GROUP_MAX overrides, tuning)
   bool use_shift = true;               // challenge products as signed rotations (shift_row_kernel) instead of transforms
-  bool use_dkey = true;                // the scalar multipliers g_i of Linear / Sum transformed once per proof and call (TERM_DKEY; RZK_DKEY=0: every row transforms them itself)
+  int use_dkey = 1;                    // the scalar multipliers g_i of Linear / Sum transformed once per proof and call (TERM_DKEY): 0 never (every row
+                                       // transforms them itself), 1 when at least kDkeyMinUses rows of the call multiply by each, 2 always (RZK_DKEY)
   Arena ws_dkey;                       // their images + norms
   const uint32_t* dkey_img = nullptr;  // images of the call in progress (set by prepare_dkey, cleared by the entry point)
   const double* dkey_l2 = nullptr;
@@ -1019,11 +1020,14 @@ int run_program_checked(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSp
 // resident key, for the TERM_DKEY terms of the call's row programs (variant bit kDkeyVar).  flags / sticky as in
 // run_program: a non-canonical coefficient clears the proof's verdict and / or raises the sticky word.  Leaves
 // c->dkey_img NULL when the path is off (RZK_DKEY=0, small rings): the callers then ask for the plain variants.
-int prepare_dkey(rzk_ctx* c, const int64_t* g, uint64_t entries, uint32_t per_entry, uint8_t* flags, bool sticky) {
+// uses: rows of this call that multiply by each multiplier.  The forward launch costs three transforms per multiplier and
+// a launch of its own; measured: Linear at l = 1 (2 uses) gains nothing, the Sum shapes (9 and 17 uses) 14-15 %.
+constexpr uint32_t kDkeyMinUses = 4;
+int prepare_dkey(rzk_ctx* c, const int64_t* g, uint64_t entries, uint32_t per_entry, uint32_t uses, uint8_t* flags, bool sticky) {
   c->dkey_img = nullptr;
   c->dkey_l2 = nullptr;
   c->dkey_n = 0;
-  if (!c->use_dkey || c->small || entries == 0) return RZK_OK;
+  if (c->use_dkey <= 0 || (c->use_dkey == 1 && uses < kDkeyMinUses) || c->small || entries == 0) return RZK_OK;
   const uint64_t count = entries * per_entry;
   const size_t img_bytes = ((size_t)count * kKeyImages * c->N * sizeof(uint32_t) + 255) & ~(size_t)255;
   int rc = arena_reserve(c, c->ws_dkey, img_bytes + (size_t)count * sizeof(double));
@@ -1182,7 +1186,7 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
   }
   if (const char* e = std::getenv("RZK_SHIFT")) c->use_shift = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_SUM_D")) c->sum_d = std::atoi(e) != 0 ? 1 : 0;
-  if (const char* e = std::getenv("RZK_DKEY")) c->use_dkey = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RZK_DKEY")) c->use_dkey = std::atoi(e);
   if (const char* e = std::getenv("RZK_PRESET_IN_KERNEL")) c->preset_in_kernel = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_PAIRS")) c->use_pairs = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_UPT")) c->units_per_task = (uint32_t)std::atoi(e);
@@ -1623,8 +1627,15 @@ int rzk_linear_commit_batch_dev(rzk_ctx* c, const int64_t* g, const int64_t* x, 
   if (rc != RZK_OK) return rc;
   int64_t* gx = (int64_t*)c->ws.p;
   int64_t* a2y = gx + B * l * c->N;
+  // the multiplier g of every proof, transformed once for the rows that multiply by it (gx, u)
+  rc = prepare_dkey(c, g, B, 1, 2 * l, nullptr, true);      // l rows of gx, l rows of u
+  if (rc != RZK_OK) return rc;
+  struct DkeyScope {
+    rzk_ctx* c;
+    ~DkeyScope() { c->dkey_img = nullptr; c->dkey_l2 = nullptr; c->dkey_n = 0; }
+  } dkey_scope{c};
   // linear.rs:91-95: gx = x_i * g
-  rc = run_program(c, PG_CMUL, l, {{x, l, 0}, {g, 1, 0}, {gx, l, 0}}, nullptr, 1, B);
+  rc = run_program(c, PG_CMUL, l | dkv(c), {{x, l, 0}, {g, 1, 0}, {gx, l, 0}}, nullptr, 1, B);
   if (rc != RZK_OK) return rc;
   const std::vector<OpSpec> c2 = {{x, l, 0}, {gx, l, 0}, {r, k, 0}, {rp, k, 0}, {y, k, 0}, {yp, k, 0}, {cm, n + l, 0},
                                   {cpm, n + l, 0}, {t, n, 0}, {tp, n, 0}, {a2y, l, 0}};
@@ -1645,7 +1656,7 @@ int rzk_linear_commit_batch_dev(rzk_ctx* c, const int64_t* g, const int64_t* x, 
     rc = run_program(c, PG_LIN_COMMIT2, 0, c2, ok, 1, B);
     if (rc != RZK_OK) return rc;
   }
-  return run_program(c, PG_LIN_U, 0, {{a2y, l, 0}, {g, 1, 0}, {yp, k, 0}, {u, l, 0}}, ok, 1, B);
+  return run_program(c, PG_LIN_U, dkv(c), {{a2y, l, 0}, {g, 1, 0}, {yp, k, 0}, {u, l, 0}}, ok, 1, B);
 }
 
 int rzk_linear_response_batch_dev(rzk_ctx* c, const int64_t* y, const int64_t* yp, const int64_t* r,
@@ -1670,17 +1681,27 @@ int rzk_linear_verify_batch_dev(rzk_ctx* c, const int64_t* z, const int64_t* zp,
   int64_t* w2 = w1 + B * l * c->N;
   const std::vector<OpSpec> v1 = {{z, k, 0}, {zp, k, 0}, {t, n, 0}, {tp, n, 0}, {cm, n + l, 0}, {cpm, n + l, 0},
                                   {d, 1, 0}, {g, 1, 0}, {w1, l, 0}, {w2, l, 0}};
+  // The verdicts are initialised first, then the multiplier's images are prepared (a non-canonical g clears its proof's
+  // verdict: nothing may preset the flags after that), then the rows.
+  rc = check_launch(c, launch_fill_u8(cfg_of(c), accept, 1, B), "flag preset");
+  if (rc != RZK_OK) return rc;
+  rc = prepare_dkey(c, g, B, 1, 2 * l, accept, false);
+  if (rc != RZK_OK) return rc;
+  struct DkeyScope {
+    rzk_ctx* c;
+    ~DkeyScope() { c->dkey_img = nullptr; c->dkey_l2 = nullptr; c->dkey_n = 0; }
+  } dkey_scope{c};
   // linear.rs:218-223: norm predicates on z and zp, fused into the rows that load them when possible
-  rc = run_program_checked(c, PG_LIN_V1, 0, v1, accept, 1, B, B, c->verify_bound, true, false);
+  rc = run_program_checked(c, PG_LIN_V1, dkv(c), v1, accept, 1, B, B, c->verify_bound, false, false);
   if (rc == RZK_E_UNSUPPORTED) {
-    rc = run_norm(c, z, k, c->verify_bound, accept, B, 0, 0, false);
+    rc = run_norm(c, z, k, c->verify_bound, accept, B, 1, 0, false);
     if (rc != RZK_OK) return rc;
     rc = run_norm(c, zp, k, c->verify_bound, accept, B, 1, 0, false);
     if (rc != RZK_OK) return rc;
-    rc = run_program(c, PG_LIN_V1, 0, v1, accept, 1, B, 0, false);
+    rc = run_program(c, PG_LIN_V1, dkv(c), v1, accept, 1, B, 0, false);
   }
   if (rc != RZK_OK) return rc;
-  return run_program(c, PG_LIN_V2, 0, {{w1, l, 0}, {w2, l, 0}, {g, 1, 0}, {d, 1, 0}, {zp, k, 0}, {u, l, 0}}, accept, 1, B, 0,
+  return run_program(c, PG_LIN_V2, dkv(c), {{w1, l, 0}, {w2, l, 0}, {g, 1, 0}, {d, 1, 0}, {zp, k, 0}, {u, l, 0}}, accept, 1, B, 0,
                      false);
 }
 
@@ -1730,7 +1751,7 @@ int rzk_sum_commit_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* gs, const in
   // (XP runs before ok is preset: a non-canonical x_i / g_i is reported through the sticky word, and again by the
   //  later rows that load the same polynomials with the flags in place)
   // the V multipliers g_i of every proof, transformed once for all the rows that multiply by them (XP, D / U)
-  rc = prepare_dkey(c, gs, B, V, nullptr, true);
+  rc = prepare_dkey(c, gs, B, V, 2 * l, nullptr, true);   // l rows of XP, l or (columns of a2) rows of U / D
   if (rc != RZK_OK) return rc;
   struct DkeyScope {   // the images belong to this call
     rzk_ctx* c;
@@ -1809,7 +1830,7 @@ int rzk_sum_verify_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* zs, const in
   if (rc != RZK_OK) return rc;
   // sum.rs:301-319.  The multipliers' images are prepared AFTER the relation rows above have initialised accept: a
   // non-canonical g_i must clear the proof's verdict, and nothing presets the flags again from here on.
-  rc = prepare_dkey(c, gs, B, V, accept, false);
+  rc = prepare_dkey(c, gs, B, V, 2 * l, accept, false);
   if (rc != RZK_OK) return rc;
   struct DkeyScope {
     rzk_ctx* c;

@@ -242,6 +242,13 @@ def test_config5_shape_vs_oracle(torch_mod):
     dict(N=1024, shape=(2, 5, 2), V=2, env={"RZK_SUM_D": 1}),
     dict(N=2048, shape=(2, 5, 2), V=3, env={"RZK_SUM_D": 1}),
     dict(N=1024, shape=(4, 9, 4), V=8, env={"RZK_SUM_D": 0}),
+    # the scalar multipliers as prepared images (TERM_DKEY) forced at shapes below the use threshold, and switched off
+    # where they are the default
+    dict(N=512, shape=(1, 3, 1), V=3, env={"RZK_DKEY": 2}),
+    dict(N=2048, shape=(1, 3, 1), V=2, env={"RZK_DKEY": 2}),
+    dict(N=1024, shape=(2, 5, 2), V=2, env={"RZK_DKEY": 2, "RZK_SUM_D": 1}),
+    dict(N=1024, shape=(4, 9, 4), V=8, env={"RZK_DKEY": 0}),
+    dict(N=2048, shape=(2, 5, 2), V=3, env={"RZK_DKEY": 0}),
 ])
 def test_forced_kernel_paths_vs_oracle(torch_mod, cfg):
     N, (n, k, l), V = cfg["N"], cfg["shape"], cfg["V"]

@@ -69,13 +69,15 @@ def test_trusted_mode_same_bytes_default_still_checks(torch_mod, N):
         assert np.array_equal(c1[b], c_ref) and np.array_equal(t1[b], t_ref) and bool(ok1[b]) == ok_ref
 
 
+@pytest.mark.parametrize("dkey", [1, 2, 0])
 @pytest.mark.parametrize("N", [512, 2048])
-def test_coefficient_of_exactly_two_to_31_is_rejected(torch_mod, N):
+def test_coefficient_of_exactly_two_to_31_is_rejected(torch_mod, N, dkey):
     """2^31 has the low word INT32_MIN and a zero high word after the +h shift: the canonical test must catch it through
     the low-word bound, in operands that carry no norm predicate as well (gs, cs of sum_verify; g, cp of
-    linear_verify) and in z."""
+    linear_verify) and in z.  dkey = 2: the multipliers g / g_i go through dkey_transform_kernel (which then is the only
+    place that sees their raw coefficients and must clear the verdict itself); 0: every row loads them."""
     n, k, l, B, V = 1, 3, 1, 3, 2
-    ctx = make_ctx(N, n, k, l)
+    ctx = make_ctx(N, n, k, l, env={"RZK_DKEY": dkey})
     P = P_of(ctx)
     rng = np.random.default_rng(4300 + N)
     A = synth.key(rng, N, n, k, l)

@@ -33,6 +33,9 @@ KNOBS = [
     {"RZK_UPT": 64, "RZK_PRESET_IN_KERNEL": 0},   # one team per entry, verdict flags preset by a fill launch (default: by the team)
     {"RZK_SUM_D": 1},       # Sum proof: a2.(sum_i g_i v_i - v') whatever the cost model says
     {"RZK_SUM_D": 0},       # ... and sum_i g_i (a2.v_i) - a2.v' row by row
+    {"RZK_DKEY": 2},        # the scalar multipliers g / g_i as prepared images whatever the use count
+    {"RZK_DKEY": 0},        # ... and transformed by every row that multiplies by them
+    {"RZK_DKEY": 2, "RZK_SUM_D": 0},
 ]
 
 

@@ -53,6 +53,8 @@ enum ProgId : int {
   PG_REL_ROT,         // w - c1(.)d - t == 0, all rotations                      } n >= 2: grouped rows + rotations
   PG_SUM_D,           // variant = V: D_c = sum_i g_i(.)v_{i,c} - v'_c for the columns c that a2 uses   } sum_i g_i (a2.v_i) - a2.v'
   PG_SUM_V4,          // a2.D - w2(.)d - u == 0                                                           }   = a2.(sum_i g_i v_i - v')
+  PG_LIN_V1B,         // Linear verifier, rearranged: relation rows, e = a2.z - c2(.)d, e' = a2.z' - c2'(.)d   } (a2.z)(.)g - a2.z' - (c2(.)g - c2')(.)d - u
+  PG_LIN_V2B,         // g(.)e - e' - u == 0                                                                     }   = g(.)e - e' - u
 };
 
 struct DevProg {
@@ -117,6 +119,7 @@ struct rzk_ctx {
   const uint32_t* dkey_img = nullptr;  // images of the call in progress (set by prepare_dkey, cleared by the entry point)
   const double* dkey_l2 = nullptr;
   uint32_t dkey_n = 0;
+  bool lin_e = true;                   // Linear verifier: g(.)(a2.z - c2(.)d) - (a2.z' - c2'(.)d) - u == 0 (one product with g; RZK_LIN_E=0: the reference's grouping)
   int sum_d = -1;                      // Sum proof: a2.(sum_i g_i v_i - v') instead of sum_i g_i (a2.v_i) - a2.v' (-1 = by cost, RZK_SUM_D=0|1 forces)
   bool preset_in_kernel = true;        // verdict flags initialised by the unit kernels themselves where one team owns an entry (RZK_PRESET_IN_KERNEL=0: always a fill launch)
   bool small = false;                  // N < 512: schoolbook kernels (rzk_kernels.hip, "small ring degrees")
@@ -509,6 +512,44 @@ int build_program(rzk_ctx* c, int id, uint32_t var_in, PB& pb) {
       }
       if (var & 1) {   // fused check_verify_constraint(z), (zp)  (linear.rs:218-223)
         if (!mark_checks(pb, 0, k) || !mark_checks(pb, 1, k)) return RZK_E_UNSUPPORTED;
+      }
+      break;
+    case PG_LIN_V1B:
+      // ops: 0 = z[k], 1 = zp[k], 2 = t[n], 3 = tp[n], 4 = c[n+l], 5 = cp[n+l], 6 = d, 7 = e[l], 8 = ep[l]
+      // linear.rs:237-249 reads (a2.z)(.)g - a2.z' == (c2(.)g - c2')(.)d + u; in a commutative ring that is
+      // g(.)(a2.z - c2(.)d) - (a2.z' - c2'(.)d) - u == 0: one product with g instead of two, and none in this program
+      for (uint32_t i = 0; i < n; ++i) {       // linear.rs:225-229
+        pb.begin_row(0, 0, MODE_ZERO);
+        key_row(c, pb, +1, i, 0, 0);
+        pb.challenge_term(rot, -1, 6, 4, i);
+        pb.add(-1, 2, i);
+      }
+      for (uint32_t i = 0; i < n; ++i) {       // linear.rs:231-235
+        pb.begin_row(0, 0, MODE_ZERO);
+        key_row(c, pb, +1, i, 1, 0);
+        pb.challenge_term(rot, -1, 6, 5, i);
+        pb.add(-1, 3, i);
+      }
+      for (uint32_t i = 0; i < l; ++i) {       // e = a2.z - c2(.)d ; c2 = last n rows of c
+        pb.begin_row(7, i, MODE_STORE);
+        key_row(c, pb, +1, n + i, 0, 0);
+        pb.challenge_term(rot, -1, 6, 4, l + i);
+      }
+      for (uint32_t i = 0; i < l; ++i) {       // e' = a2.z' - c2'(.)d
+        pb.begin_row(8, i, MODE_STORE);
+        key_row(c, pb, +1, n + i, 1, 0);
+        pb.challenge_term(rot, -1, 6, 5, l + i);
+      }
+      if (var & 1) {   // fused check_verify_constraint(z), (zp)  (linear.rs:218-223)
+        if (!mark_checks(pb, 0, k) || !mark_checks(pb, 1, k)) return RZK_E_UNSUPPORTED;
+      }
+      break;
+    case PG_LIN_V2B:   // ops: 0 = e[l], 1 = ep[l], 2 = g, 3 = u[l] : g(.)e - e' - u == 0
+      for (uint32_t i = 0; i < l; ++i) {
+        pb.begin_row(0, 0, MODE_ZERO);
+        pb.scalar_term(dk, +1, 2, 0, 0, i);
+        pb.add(-1, 1, i);
+        pb.add(-1, 3, i);
       }
       break;
     case PG_LIN_V2:
@@ -1187,6 +1228,7 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
   if (const char* e = std::getenv("RZK_SHIFT")) c->use_shift = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_SUM_D")) c->sum_d = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("RZK_DKEY")) c->use_dkey = std::atoi(e);
+  if (const char* e = std::getenv("RZK_LIN_E")) c->lin_e = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_PRESET_IN_KERNEL")) c->preset_in_kernel = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_PAIRS")) c->use_pairs = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_UPT")) c->units_per_task = (uint32_t)std::atoi(e);
@@ -1681,6 +1723,28 @@ int rzk_linear_verify_batch_dev(rzk_ctx* c, const int64_t* z, const int64_t* zp,
   int64_t* w2 = w1 + B * l * c->N;
   const std::vector<OpSpec> v1 = {{z, k, 0}, {zp, k, 0}, {t, n, 0}, {tp, n, 0}, {cm, n + l, 0}, {cpm, n + l, 0},
                                   {d, 1, 0}, {g, 1, 0}, {w1, l, 0}, {w2, l, 0}};
+  if (c->lin_e && !c->small) {
+    // rearranged (PG_LIN_V1B / V2B): no product with g in the first program, so it runs on the unit kernel (and
+    // initialises the verdicts itself where one team owns a proof); w1 / w2 hold e / e'
+    const std::vector<OpSpec> v1b = {{z, k, 0}, {zp, k, 0}, {t, n, 0}, {tp, n, 0}, {cm, n + l, 0}, {cpm, n + l, 0},
+                                     {d, 1, 0}, {w1, l, 0}, {w2, l, 0}};
+    rc = run_program_checked(c, PG_LIN_V1B, 0, v1b, accept, 1, B, B, c->verify_bound, true, false);
+    if (rc == RZK_E_UNSUPPORTED) {
+      rc = run_norm(c, z, k, c->verify_bound, accept, B, 0, 0, false);
+      if (rc != RZK_OK) return rc;
+      rc = run_norm(c, zp, k, c->verify_bound, accept, B, 1, 0, false);
+      if (rc != RZK_OK) return rc;
+      rc = run_program(c, PG_LIN_V1B, 0, v1b, accept, 1, B, 0, false);
+    }
+    if (rc != RZK_OK) return rc;
+    rc = prepare_dkey(c, g, B, 1, l, accept, false);   // (after the verdicts exist; l rows multiply by g)
+    if (rc != RZK_OK) return rc;
+    struct DkeyScopeE {
+      rzk_ctx* c;
+      ~DkeyScopeE() { c->dkey_img = nullptr; c->dkey_l2 = nullptr; c->dkey_n = 0; }
+    } dkey_scope_e{c};
+    return run_program(c, PG_LIN_V2B, dkv(c), {{w1, l, 0}, {w2, l, 0}, {g, 1, 0}, {u, l, 0}}, accept, 1, B, 0, false);
+  }
   // The verdicts are initialised first, then the multiplier's images are prepared (a non-canonical g clears its proof's
   // verdict: nothing may preset the flags after that), then the rows.
   rc = check_launch(c, launch_fill_u8(cfg_of(c), accept, 1, B), "flag preset");

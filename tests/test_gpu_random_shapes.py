@@ -36,6 +36,9 @@ KNOBS = [
     {"RZK_DKEY": 2},        # the scalar multipliers g / g_i as prepared images whatever the use count
     {"RZK_DKEY": 0},        # ... and transformed by every row that multiplies by them
     {"RZK_DKEY": 2, "RZK_SUM_D": 0},
+    {"RZK_LIN_E": 0},       # Linear verifier in the reference's grouping (two products with g) instead of g(.)e - e' - u
+    {"RZK_LIN_E": 0, "RZK_DKEY": 2},
+    {"RZK_SHIFT": 0, "RZK_DKEY": 2},
 ]
 
 

@@ -319,6 +319,8 @@ int rzk_prof_read_kernels(rzk_ctx* ctx, char* buf, size_t cap, size_t* needed);
  *   RZK_BLOCK_MIN_LOGN=<L> row blocks (row_block_kernel) from ring degree 2^L on (default 11; 12 = never, 10 = also N = 1024)
  *   RZK_SLOT_SHARE_MIN=<x> shared-operand path when (operand transforms) / (distinct operands) >= x (default 2.0; 0 = never)
  *   RZK_PAIR_POLY=0        N = 2048: one wavefront per polynomial instead of two (default 1)
+ *   RZK_OIMG=0             Sum proof: the rows of D = sum_i g_i v_i transform v_{i,c} themselves (default 1: they read the transforms the
+ *                          a1.v_i key products of the same call left behind, where those ran on the group / block kernels)
  *   RZK_LIN_E=0            Linear verifier: the reference's grouping (a2.z)(.)g - a2.z' == (c2(.)g - c2')(.)d + u with its two products by g
  *                          (default 1: g(.)(a2.z - c2(.)d) - (a2.z' - c2'(.)d) - u == 0, one product)
  *   RZK_DKEY=0|1|2         the scalar multipliers g / g_i of the Linear / Sum proofs transformed once per proof and call into the

@@ -70,6 +70,7 @@ struct DevProg {
   uint32_t np_store = 0;
   uint32_t ngroups = 0;   // > 0: row groups (row_group_kernel)
   bool has_dkey = false;  // products with prepared multiplier images (TERM_DKEY): row_kernel only
+  bool has_dd = false;    // ... whose other operand may come from the call's operand images (TERM_DD): row_kernel<.., DD>
   bool shift = false;     // every product has the sparse challenge as multiplier: shift_row_kernel
   bool has_shift = false; // some rows end with challenge products evaluated by rotations inside row_kernel
   bool two_bit = false;   // two-bit verdict flags (CHECK2 marks)
@@ -119,6 +120,10 @@ struct rzk_ctx {
   const uint32_t* dkey_img = nullptr;  // images of the call in progress (set by prepare_dkey, cleared by the entry point)
   const double* dkey_l2 = nullptr;
   uint32_t dkey_n = 0;
+  bool use_oimg = true;                // Sum proof: the transforms of y_i / z_i that the a1 key products compute anyway are kept for the D rows (RZK_OIMG=0: off)
+  Arena ws_oimg;
+  Operands oimg_state{};               // oimg* fields of the call in progress (oimg == NULL: none); oimg_op is set per launch
+  uint32_t oimg_producer_op = 0xffu;   // != 0xff: the next launches store the images of this operand's columns
   bool lin_e = true;                   // Linear verifier: g(.)(a2.z - c2(.)d) - (a2.z' - c2'(.)d) - u == 0 (one product with g; RZK_LIN_E=0: the reference's grouping)
   int sum_d = -1;                      // Sum proof: a2.(sum_i g_i v_i - v') instead of sum_i g_i (a2.v_i) - a2.v' (-1 = by cost, RZK_SUM_D=0|1 forces)
   bool preset_in_kernel = true;        // verdict flags initialised by the unit kernels themselves where one team owns an entry (RZK_PRESET_IN_KERNEL=0: always a fill launch)
@@ -247,10 +252,14 @@ struct PB {
     p.rows[cur].nterms++;
   }
   // a product with one of the entry's scalar multipliers (operand gop, index idx): its image when the call prepared
-  // them (dk), a vector x vector term otherwise
-  void scalar_term(bool dk, int sign, uint8_t gop, uint32_t idx, uint8_t bop, uint32_t boff) {
-    if (dk) dkey_term(sign, idx, bop, boff);
-    else vec_term(sign, bop, boff, gop, idx);
+  // them (dk), a vector x vector term otherwise; oi: the other operand's transform may come from the call's operand images
+  void scalar_term(bool dk, int sign, uint8_t gop, uint32_t idx, uint8_t bop, uint32_t boff, bool oi = false) {
+    if (dk) {
+      dkey_term(sign, idx, bop, boff);
+      if (oi && !overflow) p.terms[p.nterms - 1].kind = TERM_DD;
+    } else {
+      vec_term(sign, bop, boff, gop, idx);
+    }
   }
   void vec_term(int sign, uint8_t aop, uint32_t aoff, uint8_t bop, uint32_t boff) {
     if (cur < 0 || p.nterms >= (uint32_t)kMaxTerms || aoff > 0xffff || boff > 0xffff || p.rows[cur].nshift) { overflow = true; return; }
@@ -341,12 +350,13 @@ bool shift_ok(const rzk_ctx* c) { return c->use_shift && !c->small && (c->logn <
 
 // bit of a program variant: products with the entry's scalar multipliers (g, g_i) take their prepared images (TERM_DKEY)
 constexpr uint32_t kDkeyVar = 0x10000u;
+constexpr uint32_t kOimgVar = 0x20000u;   // ... and (PG_SUM_D) the other operand's transform from the call's operand images (TERM_DD)
 
 int build_program(rzk_ctx* c, int id, uint32_t var_in, PB& pb) {
   const uint32_t n = c->n, k = c->k, l = c->l;
   const bool rot = shift_ok(c);   // challenge products inside mixed rows as rotations
-  const bool dk = (var_in & kDkeyVar) != 0;
-  const uint32_t var = var_in & ~kDkeyVar;
+  const bool dk = (var_in & kDkeyVar) != 0, oi = (var_in & kOimgVar) != 0;
+  const uint32_t var = var_in & ~(kDkeyVar | kOimgVar);
   switch (id) {
     case PG_MATVEC: {   // ops: 0 = v[k], 1 = addend[rows], 2 = out[rows]
       const uint32_t which = var >> 1;
@@ -600,7 +610,7 @@ int build_program(rzk_ctx* c, int id, uint32_t var_in, PB& pb) {
         for (uint32_t j = 0; j < l; ++j) used = used || c->key_class[(n + j) * k + col] != KC_ZERO;
         if (!used) continue;
         pb.begin_row(3, col, MODE_STORE);
-        for (uint32_t i = 0; i < var; ++i) pb.scalar_term(dk, +1, 1, i, 0, i * k + col);
+        for (uint32_t i = 0; i < var; ++i) pb.scalar_term(dk, +1, 1, i, 0, i * k + col, oi);
         pb.add(-1, 2, col);
       }
       break;
@@ -645,7 +655,9 @@ int get_program(rzk_ctx* c, int id, uint32_t var, DevProg& out) {
     dp.shift = all;
   }
   for (uint32_t r = 0; r < pb.p.nrows; ++r) dp.has_shift = dp.has_shift || pb.p.rows[r].nshift > 0;
-  for (uint32_t t = 0; t < pb.p.nterms; ++t) dp.has_dkey = dp.has_dkey || (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_DKEY;
+  for (uint32_t t = 0; t < pb.p.nterms; ++t) dp.has_dd = dp.has_dd || (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_DD;
+  for (uint32_t t = 0; t < pb.p.nterms; ++t)
+    dp.has_dkey = dp.has_dkey || (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_DKEY || (pb.p.terms[t].kind & TERM_KIND_MASK) == TERM_DD;
   dp.two_bit = pb.two_bit;
   // Row blocks: key-only programs whose rows share operands; consecutive rows are packed into blocks of at
   // most kBlockMaxRows rows and kBlockMaxSlots distinct operands.  Used when every operand is needed by at
@@ -922,6 +934,18 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
   ops.bad = sticky ? c->d_bad : nullptr;
   ops.trusted = c->trusted ? 1u : 0u;
   ops.preset = preset_in_kernel ? preset_value : 0u;
+  if (c->oimg_state.oimg) {   // operand images of the call in progress: this launch stores (producer op) and / or reads them
+    ops.oimg = c->oimg_state.oimg;
+    ops.oimg_l2 = c->oimg_state.oimg_l2;
+    ops.oimg_np = c->oimg_state.oimg_np;
+    ops.oimg_n = c->oimg_state.oimg_n;
+    ops.oimg_group = c->oimg_state.oimg_group;
+    ops.oimg_k = c->oimg_state.oimg_k;
+    std::memcpy(ops.oimg_col, c->oimg_state.oimg_col, sizeof(ops.oimg_col));
+    ops.oimg_op = c->oimg_producer_op;
+  } else {
+    ops.oimg_op = 0xffu;
+  }
   if (dp.has_dkey) {
     if (!c->dkey_img || c->small) return fail(c, RZK_E_STATE, "multiplier images not prepared");
     ops.dkey_img = c->dkey_img;
@@ -951,7 +975,8 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
     else if (dp.ngroups) pi.kernel = "row_group_kernel<" + L + ", " + std::to_string(c->logn >= 11 ? 2 : RZK_GROUP_GM) + ">";
     else if (dp.d_slots) pi.kernel = "fwd_slots_kernel<" + L + "> + row_slots_kernel<" + L + ">";
     else if (row_path)
-      pi.kernel = "row_kernel<" + L + ", " + (dp.has_shift ? "true" : "false") + (pairs ? ", PairTeam>" : ">");
+      pi.kernel = "row_kernel<" + L + ", " + (dp.has_shift ? "true" : "false") + (pairs ? ", PairTeam" : (dp.has_dd ? ", WaveTeam" : "")) +
+                  (dp.has_dd && !dp.has_shift ? ", true>" : ">");
     else if (!dp.has_vec && c->unit_io && !(c->logn == 11 && dp.has_shift))
       pi.kernel = "unit_io_kernel<" + L + ", " + (dp.has_shift ? "true" : "false") + (pairs ? ", PairTeam>" : ">");
     else
@@ -1007,7 +1032,7 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
   } else {
     if (row_path) {
       lrc = launch_rows((int)c->logn, cfg_of(c), dp.d, dp.nrows, dp.has_shift, ops, c->d_key_ntt, c->d_key_l2, c->dT, c->d_tw,
-                        c->d_row_scratch, flags, batch);
+                        c->d_row_scratch, flags, batch, dp.has_dd);
     } else {
       lrc = launch_units((int)c->logn, cfg_of(c), dp.d, dp.d_wp, dp.nunits, upt, 2 * dp.work, dp.has_vec, dp.has_shift, ops,
                          c->d_key_ntt, c->d_key_l2, c->dT, c->d_tw, c->d_row_scratch, flags, batch);
@@ -1064,11 +1089,14 @@ int run_program_checked(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSp
 // uses: rows of this call that multiply by each multiplier.  The forward launch costs three transforms per multiplier and
 // a launch of its own; measured: Linear at l = 1 (2 uses) gains nothing, the Sum shapes (9 and 17 uses) 14-15 %.
 constexpr uint32_t kDkeyMinUses = 4;
+bool dkey_wanted(const rzk_ctx* c, uint32_t uses) {
+  return !(c->use_dkey <= 0 || (c->use_dkey == 1 && uses < kDkeyMinUses) || c->small);
+}
 int prepare_dkey(rzk_ctx* c, const int64_t* g, uint64_t entries, uint32_t per_entry, uint32_t uses, uint8_t* flags, bool sticky) {
   c->dkey_img = nullptr;
   c->dkey_l2 = nullptr;
   c->dkey_n = 0;
-  if (c->use_dkey <= 0 || (c->use_dkey == 1 && uses < kDkeyMinUses) || c->small || entries == 0) return RZK_OK;
+  if (!dkey_wanted(c, uses) || entries == 0) return RZK_OK;
   const uint64_t count = entries * per_entry;
   const size_t img_bytes = ((size_t)count * kKeyImages * c->N * sizeof(uint32_t) + 255) & ~(size_t)255;
   int rc = arena_reserve(c, c->ws_dkey, img_bytes + (size_t)count * sizeof(double));
@@ -1103,6 +1131,39 @@ int prepare_dkey(rzk_ctx* c, const int64_t* g, uint64_t entries, uint32_t per_en
 }
 // variant bit for programs that multiply by the call's scalar multipliers
 uint32_t dkv(const rzk_ctx* c) { return c->dkey_img ? kDkeyVar : 0u; }
+
+// Operand images of a Sum call (Operands::oimg): room for the transforms of the columns a2 uses of every (proof, summand)
+// vector, all marked "nothing stored yet".  Leaves c->oimg_state.oimg NULL when the path is off or nothing would be saved.
+bool sum_uses_d(const rzk_ctx* c, uint32_t V);   // (below, with the Sum entry points)
+int prepare_oimg(rzk_ctx* c, uint64_t B, uint32_t V, uint32_t uses) {
+  c->oimg_state = Operands{};
+  c->oimg_producer_op = 0xffu;
+  if (!c->use_oimg || !dkey_wanted(c, uses) || c->k > 32u || !sum_uses_d(c, V)) return RZK_OK;
+  const uint32_t n = c->n, k = c->k, l = c->l;
+  uint32_t ncols = 0;
+  for (uint32_t col = 0; col < 32u; ++col) c->oimg_state.oimg_col[col] = -1;
+  for (uint32_t col = 0; col < k; ++col) {
+    bool used = false;
+    for (uint32_t j = 0; j < l; ++j) used = used || c->key_class[(n + j) * k + col] != KC_ZERO;
+    if (used) c->oimg_state.oimg_col[col] = (int8_t)ncols++;
+  }
+  if (ncols == 0) return RZK_OK;
+  const uint64_t slots = B * V * ncols;
+  const size_t img_bytes = ((size_t)slots * kKeyImages * c->N * sizeof(uint32_t) + 255) & ~(size_t)255;
+  const size_t l2_bytes = ((size_t)slots * sizeof(double) + 255) & ~(size_t)255;
+  int rc = arena_reserve(c, c->ws_oimg, img_bytes + l2_bytes + slots);
+  if (rc != RZK_OK) return rc;
+  char* base = (char*)c->ws_oimg.p;
+  HIPCHK(c, hipMemsetAsync(base + img_bytes + l2_bytes, 0, slots, c->stream));
+  c->oimg_state.oimg = (uint32_t*)base;
+  c->oimg_state.oimg_l2 = (double*)(base + img_bytes);
+  c->oimg_state.oimg_np = (uint8_t*)(base + img_bytes + l2_bytes);
+  c->oimg_state.oimg_n = ncols;
+  c->oimg_state.oimg_group = V;
+  c->oimg_state.oimg_k = k;
+  return RZK_OK;
+}
+uint32_t oiv(const rzk_ctx* c) { return (c->oimg_state.oimg && c->dkey_img) ? kOimgVar : 0u; }
 
 bool can_fuse(rzk_ctx* c, int id, uint32_t var, uint64_t bound) {
   DevProg dp;
@@ -1229,6 +1290,7 @@ int rzk_ctx_create(rzk_ctx** out, int64_t q, uint32_t N, uint32_t n, uint32_t k,
   if (const char* e = std::getenv("RZK_SUM_D")) c->sum_d = std::atoi(e) != 0 ? 1 : 0;
   if (const char* e = std::getenv("RZK_DKEY")) c->use_dkey = std::atoi(e);
   if (const char* e = std::getenv("RZK_LIN_E")) c->lin_e = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RZK_OIMG")) c->use_oimg = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_PRESET_IN_KERNEL")) c->preset_in_kernel = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_PAIRS")) c->use_pairs = std::atoi(e) != 0;
   if (const char* e = std::getenv("RZK_UPT")) c->units_per_task = (uint32_t)std::atoi(e);
@@ -1281,6 +1343,7 @@ void rzk_ctx_destroy(rzk_ctx* c) {
   if (c->ws.p) (void)hipFree(c->ws.p);
   if (c->ws_slots.p) (void)hipFree(c->ws_slots.p);
   if (c->ws_dkey.p) (void)hipFree(c->ws_dkey.p);
+  if (c->ws_oimg.p) (void)hipFree(c->ws_oimg.p);
   if (c->stage.p) (void)hipFree(c->stage.p);
   if (c->dT) (void)hipFree(c->dT);
   if (c->d_tw) (void)hipFree(c->d_tw);
@@ -1823,6 +1886,13 @@ int rzk_sum_commit_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* gs, const in
   } dkey_scope{c};
   rc = run_program(c, PG_SUM_XP, V | dkv(c), {{xs, V * l, 0}, {gs, V, 0}, {xp, l, 0}}, nullptr, 1, B);
   if (rc != RZK_OK) return rc;
+  // the a1.y_i key products below leave the transforms of y_i's a2-columns for the D rows (operand 2 of the summand launch)
+  rc = prepare_oimg(c, B, V, 2 * l);
+  if (rc != RZK_OK) return rc;
+  struct OimgScope {
+    rzk_ctx* c;
+    ~OimgScope() { c->oimg_state = Operands{}; c->oimg_producer_op = 0xffu; }
+  } oimg_scope{c};
   // sum.rs:116 and 151: cp = commit(xp; rp), tp = a1.yp
   const std::vector<OpSpec> cp_specs = {{xp, l, 0}, {rp, k, 0}, {yp, k, 0}, {cpm, n + l, 0}, {tp, n, 0}};
   const std::vector<OpSpec> cs_specs = {{xs, l, 0}, {rs, k, 0}, {ys, k, 0}, {cs, n + l, 0}, {ts, n, 0}};
@@ -1832,7 +1902,9 @@ int rzk_sum_commit_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* gs, const in
     rc = run_program_checked(c, PG_OPEN_COMMIT, 0, cp_specs, ok, 1, B, B, c->commit_bound, true);
     if (rc != RZK_OK) return rc;
     // sum.rs:117-120 and 145-148: c_i = commit(x_i; r_i), t_i = a1.y_i — the V summands are extra batch entries
+    c->oimg_producer_op = 2;
     rc = run_program_checked(c, PG_OPEN_COMMIT, 0, cs_specs, ok, V, B * V, B, c->commit_bound, false);
+    c->oimg_producer_op = 0xffu;
     if (rc != RZK_OK) return rc;
   } else {
     if (ok) {
@@ -1843,13 +1915,15 @@ int rzk_sum_commit_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* gs, const in
     }
     rc = run_program(c, PG_OPEN_COMMIT, 0, cp_specs, ok, 1, B);
     if (rc != RZK_OK) return rc;
+    c->oimg_producer_op = 2;
     rc = run_program(c, PG_OPEN_COMMIT, 0, cs_specs, ok, V, B * V);
+    c->oimg_producer_op = 0xffu;
     if (rc != RZK_OK) return rc;
   }
   // sum.rs:154-160: u = sum_i (a2.y_i)(.)g_i - a2.yp
   if (sum_uses_d(c, V)) {   // = a2.(sum_i g_i(.)y_i - yp): D (k polynomials per proof, the columns a2 uses) lives where w would
     int64_t* D = w;
-    rc = run_program(c, PG_SUM_D, V | dkv(c), {{ys, V * k, 0}, {gs, V, 0}, {yp, k, 0}, {D, k, 0}}, ok, 1, B);
+    rc = run_program(c, PG_SUM_D, V | dkv(c) | oiv(c), {{ys, V * k, 0}, {gs, V, 0}, {yp, k, 0}, {D, k, 0}}, ok, 1, B);
     if (rc != RZK_OK) return rc;
     return run_program(c, PG_MATVEC, RZK_KEY_A2 * 2, {{D, k, 0}, {nullptr, l, 0}, {u, l, 0}}, ok, 1, B);
   }
@@ -1888,7 +1962,16 @@ int rzk_sum_verify_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* zs, const in
   const std::vector<OpSpec> rel_p = {{zp, k, 0}, {tp, n, 0}, {cpm, n + l, 0}, {d, 1, 0}};
   // sum.rs:262-271 norm predicates ride on sum.rs:278-291 (every summand; batch entries B*V, flag per proof)
   // and sum.rs:294-298
+  // (the a1.z_i key products leave the transforms of z_i's a2-columns for the D rows: operand 0 of their launch)
+  rc = prepare_oimg(c, B, V, 2 * l);
+  if (rc != RZK_OK) return rc;
+  struct OimgScope {
+    rzk_ctx* c;
+    ~OimgScope() { c->oimg_state = Operands{}; c->oimg_producer_op = 0xffu; }
+  } oimg_scope{c};
+  c->oimg_producer_op = 0;
   rc = run_a1_relation(c, rel_s, w0, accept, V, B * V, B, true);
+  c->oimg_producer_op = 0xffu;
   if (rc != RZK_OK) return rc;
   rc = run_a1_relation(c, rel_p, w0, accept, 1, B, B, false);
   if (rc != RZK_OK) return rc;
@@ -1902,7 +1985,7 @@ int rzk_sum_verify_batch_dev(rzk_ctx* c, uint32_t V, const int64_t* zs, const in
   } dkey_scope{c};
   if (by_d) {   // lhs = a2.(sum_i g_i(.)z_i - zp): D in w1's place, then one relation row per row of a2
     int64_t* D = w1;
-    rc = run_program(c, PG_SUM_D, V | dkv(c), {{zs, V * k, 0}, {gs, V, 0}, {zp, k, 0}, {D, k, 0}}, accept, 1, B, 0, false);
+    rc = run_program(c, PG_SUM_D, V | dkv(c) | oiv(c), {{zs, V * k, 0}, {gs, V, 0}, {zp, k, 0}, {D, k, 0}}, accept, 1, B, 0, false);
     if (rc != RZK_OK) return rc;
     rc = run_program(c, PG_SUM_W2, V | dkv(c), {{cs, V * (n + l), 0}, {gs, V, 0}, {cpm, n + l, 0}, {w2, l, 0}}, accept, 1, B, 0, false);
     if (rc != RZK_OK) return rc;

@@ -51,7 +51,7 @@ constexpr int kMaxAdds = 128;
 // TERM_SHIFT: (a_op,a_off) (*) (b_op,b_off) with a sparse `a` (the challenge d), evaluated as signed negacyclic
 // rotations (ShiftGeo, rzk_core.h) instead of transforms.  A row keeps its shift terms behind its transform
 // terms: terms[term0 .. term0+nterms) are KEY / VEC, terms[term0+nterms .. +nshift) are SHIFT.
-enum : uint8_t { TERM_KEY = 0, TERM_VEC = 1, TERM_SHIFT = 2, TERM_DKEY = 3, TERM_KIND_MASK = 0x3f };
+enum : uint8_t { TERM_KEY = 0, TERM_VEC = 1, TERM_SHIFT = 2, TERM_DKEY = 3, TERM_DD = 4, TERM_KIND_MASK = 0x3f };
 enum : uint8_t { MODE_STORE = 0, MODE_ZERO = 1 };
 // Fused norm predicate (Params::check_*_constraint, src/params.rs:102-118): a term (its b operand) or an
 // addition marked with CHECK also tests sum c^2 < Operands::norm_limit for the polynomial it loads and
@@ -68,6 +68,8 @@ constexpr uint8_t ADD_OP_MASK = 0x3f;
 struct alignas(8) Term {
   uint8_t kind;     // TERM_KEY: KEY[a_off] (*) operand(b_op, b_off);  TERM_VEC: (a_op,a_off) (*) (b_op,b_off);
                     // TERM_DKEY: image a_off of the batch entry's own multipliers (Operands::dkey_img) (*) operand(b_op, b_off)
+                    // TERM_DD: the same, and the operand's transform is taken from Operands::oimg when an earlier launch
+                    //          of the call left it there (b_off = summand * oimg_k + column); transformed here otherwise
   int8_t sign;      // +1 / -1
   uint8_t a_op, b_op;
   uint16_t a_off, b_off;
@@ -188,6 +190,16 @@ struct Operands {
   const uint32_t* dkey_img;
   const double* dkey_l2;
   uint32_t dkey_n, pad3;
+  // Operand images: the key-product kernels that transform the vectors y_i (z_i) of a Sum call anyway — row_group_kernel,
+  // row_block_kernel evaluating a1.y_i (a1.z_i) — leave the transforms of the columns a2 uses here (producer: oimg_op =
+  // that operand's index, entry = batch entry), and the vector x vector rows of D = sum_i g_i (.) v_i read them back
+  // (consumer, TERM_DD: entry = proof * oimg_group + summand) instead of transforming v_{i,c} again.
+  // [entry][oimg_n][kKeyImages][N] lazy residues in the NTT-domain layout; oimg_l2 2-norm bounds; oimg_np primes stored.
+  uint32_t* oimg;
+  double* oimg_l2;
+  uint8_t* oimg_np;
+  uint32_t oimg_n, oimg_op, oimg_group, oimg_k;
+  int8_t oimg_col[32];   // column of the vector -> image index, or -1
 };
 
 // ---- launchers (defined in rzk_kernels.hip) --------------------------------------------------------------------
@@ -203,7 +215,7 @@ struct LaunchCfg {
 // row_kernel: one wavefront per (batch entry, row); programs with vector x vector products
 int launch_rows(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows, bool has_shift, const Operands& ops,
                 const uint32_t* d_key_ntt, const double* d_key_l2, const DevTables* d_T, const uint32_t* d_tw,
-                uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch);
+                uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch, bool has_dd = false);
 // work_per_entry: transforms one batch entry costs at two primes (the progress priorities only need an estimate)
 int launch_units(int logn, const LaunchCfg& cfg, const Program* d_prog, const WaveProgram* d_wp, uint32_t nunits,
                  uint32_t units_per_task, uint32_t work_per_entry, bool has_vec, bool has_shift, const Operands& ops,

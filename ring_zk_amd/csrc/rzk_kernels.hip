@@ -821,8 +821,26 @@ __device__ __forceinline__ void shift_product(uint32_t* res, bool fresh, bool mi
   }
 }
 
+// Producer side of Operands::oimg: the transform x (prime pi) of operand (op, off) of batch entry b, as it leaves wave_fwd
+template <int LOGN, class TM>
+__device__ __forceinline__ void store_operand_image(const uint32_t* x, const Operands& ops, uint32_t op, uint32_t off, uint32_t b,
+                                                    int pi, int lane, float nrm2, bool first) {
+  using G = Geo<LOGN, TM::LL>;
+  if (!ops.oimg || op != ops.oimg_op || off >= 32u) return;
+  const int ci = ops.oimg_col[off];
+  if (ci < 0) return;
+  const size_t oslot = (size_t)b * ops.oimg_n + (uint32_t)ci;
+  uint4* __restrict__ dst = reinterpret_cast<uint4*>(ops.oimg + (oslot * kKeyImages + pi) * G::N);
+#pragma unroll
+  for (int g = 0; g < G::E / 4; ++g) dst[G::key4(lane, g)] = make_uint4(x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]);
+  if (lane == 0) {
+    if (first) ops.oimg_l2[oslot] = (double)nrm2;
+    ops.oimg_np[oslot] = (uint8_t)(pi + 1);   // primes 0 .. pi are there (the passes run in this order)
+  }
+}
+
 // acc +/- (term) for prime `pi`, transforming the term's operands in the wave.
-template <int LOGN, bool HAS_VEC, bool OPQ = false, class TM = WaveTeam>
+template <int LOGN, bool HAS_VEC, bool OPQ = false, class TM = WaveTeam, bool DD = false>
 __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const Operands& ops, uint32_t b,
                                             uint32_t bo, int lane, uint32_t* lds, const uint32_t* __restrict__ twf,
                                             const PrimeConsts& pc, int pi, const uint32_t* __restrict__ key_ntt,
@@ -839,9 +857,31 @@ __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const 
   bool below = true, fault = false;
   const bool chk = first && (tm.kind & (TERM_CHECK | TERM_CHECK2));
   const bool trusted = ops.trusted != 0;
-  load_lift<LOGN, TM, RZK_ROW_MODE_B>(x, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), ln, pc, first, nb, chk, ops.norm_limit, below, qhalf, trusted, fault);
-  if (chk && !below && (lane & 63) == 0) fail_check(flags + bo, ops.pad != 0, (tm.kind & TERM_CHECK2) != 0);
-  wave_fwd<LOGN, TM>(x, ln, lds, twf, pc);
+  // TERM_DD: the operand's transform under this prime may already lie in the call's operand images
+  bool from_image = false;
+  size_t oslot = 0;
+  if (DD && (tm.kind & TERM_KIND_MASK) == TERM_DD && ops.oimg) {   // (DD is a template flag: as a run-time test in every row kernel it changed the compiler's load scheduling of the ordinary rows — Linear -2 %)
+    const uint32_t summand = tm.b_off / ops.oimg_k, col = tm.b_off - summand * ops.oimg_k;
+    const int ci = col < 32u ? ops.oimg_col[col] : -1;
+    if (ci >= 0) {
+      oslot = ((size_t)bo * ops.oimg_group + summand) * ops.oimg_n + (uint32_t)ci;
+      from_image = (int)ops.oimg_np[oslot] > pi;
+    }
+  }
+  if (DD) from_image = __builtin_amdgcn_readfirstlane((int)from_image) != 0;
+  if (DD && from_image) {
+    const uint4* __restrict__ ip = reinterpret_cast<const uint4*>(ops.oimg + (oslot * kKeyImages + pi) * N);
+#pragma unroll
+    for (int g = 0; g < E / 4; ++g) {
+      const uint4 iv = ip[G::key4(ln, g)];
+      x[4 * g] = iv.x, x[4 * g + 1] = iv.y, x[4 * g + 2] = iv.z, x[4 * g + 3] = iv.w;
+    }
+    nb = (float)ops.oimg_l2[oslot];
+  } else {
+    load_lift<LOGN, TM, RZK_ROW_MODE_B>(x, operand_ptr(ops, tm.b_op, tm.b_off, b, bo, N), ln, pc, first, nb, chk, ops.norm_limit, below, qhalf, trusted, fault);
+    if (chk && !below && (lane & 63) == 0) fail_check(flags + bo, ops.pad != 0, (tm.kind & TERM_CHECK2) != 0);
+    wave_fwd<LOGN, TM>(x, ln, lds, twf, pc);
+  }
   if (HAS_VEC && (tm.kind & TERM_KIND_MASK) == TERM_VEC) {
     // product of two per-proof polynomials: fold N^-1 and the Montgomery factor into one of them
     uint32_t xb[E];
@@ -861,7 +901,7 @@ __device__ __forceinline__ void term_direct(uint32_t* acc, const Term tm, const 
     }
   } else {
     // resident key entry, or (TERM_DKEY) one of the batch entry's own multiplier images — same form, same use
-    const bool dk = (tm.kind & TERM_KIND_MASK) == TERM_DKEY;
+    const bool dk = (tm.kind & TERM_KIND_MASK) == TERM_DKEY || (tm.kind & TERM_KIND_MASK) == TERM_DD;
     const size_t image = dk ? (size_t)bo * ops.dkey_n + tm.a_off : (size_t)tm.a_off;
     if (first) bound = bound_fma((float)(dk ? ops.dkey_l2[image] : key_l2[image]), nb, bound);
     const uint4* __restrict__ kp = reinterpret_cast<const uint4*>((dk ? ops.dkey_img : key_ntt) + (image * kKeyImages + pi) * N);
@@ -1933,7 +1973,7 @@ unit_io_kernel(const Program* __restrict__ prog, const WaveProgram* __restrict__
 // unit_kernel's parked sums and global state lines: 1.36 vs 1.85 ms per launch for the Sum rows at (4,9,4), V = 8).
 // Primes one after the other; the first pass measures the operands (prime count, canonical test, norm marks).
 // =============================================================================================
-template <int LOGN, bool HAS_SHIFT, class TM = WaveTeam>
+template <int LOGN, bool HAS_SHIFT, class TM = WaveTeam, bool DD = false>
 __global__ void __launch_bounds__(TM::kTeamsPerBlock << TM::LL, (LOGN <= 10 || TM::LL == 7 ? 4 : 1))   // N <= 1024 and teams of two: hold the 4 waves per SIMD the LDS allows
 row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t* __restrict__ key_ntt,
            const double* __restrict__ key_l2, const DevTables* __restrict__ Tp, const uint32_t* __restrict__ tw_all,
@@ -2011,8 +2051,8 @@ row_kernel(const Program* __restrict__ prog, const Operands ops, const uint32_t*
         for (int c = 0; c < E; ++c) acc[c] = 0;
 #pragma unroll 1
         for (uint32_t t = 0; t < row.nterms; ++t)
-          term_direct<LOGN, true, OPQ, TM>(acc, table_load(&prog->terms[row.term0 + t]), ops, b, bo, lane, lds, twf, pc, pi, key_ntt,
-                                       key_l2, first, bound, flags, qhalf);
+          term_direct<LOGN, true, OPQ, TM, DD>(acc, table_load(&prog->terms[row.term0 + t]), ops, b, bo, lane, lds, twf, pc, pi, key_ntt,
+                                           key_l2, first, bound, flags, qhalf);
         if (first) np = primes_for(bound, T);
         inverse_and_fold<LOGN, OPQ, TM>(pi, np, acc, lane, lds, twf + kTableLen, pc, st_lds, st_glb, T);
       }
@@ -2214,6 +2254,7 @@ row_group_kernel(const Program* __restrict__ prog, const Operands ops, const uin
           if (chk && !below && lane == 0) flags[bo] = 0;
           if (fault) input_fault(ops, flags, bo, lane);
           wave_fwd<LOGN>(x, ln, lds, twf, pc);
+          store_operand_image<LOGN, WaveTeam>(x, ops, tm0.b_op, tm0.b_off, b, pi, ln, nb, first);
 #pragma unroll
           for (int g = 0; g < GM; ++g) {
             if ((uint32_t)g < cnt) {
@@ -2326,6 +2367,7 @@ row_block_kernel(const Program* __restrict__ prog, const BlockPlan* __restrict__
         if (fault) input_fault(ops, flags, bo, lane);
         if (first && lane == 0) norm1[s] = nb;
         wave_fwd<LOGN, TM>(x, ln, lds, twf, pc);
+        store_operand_image<LOGN, TM>(x, ops, plan->slot_op[gs], plan->slot_off[gs], b, pi, ln, nb, first);
         uint32_t* dst = staged + s * N + ln;
 #pragma unroll
         for (int c = 0; c < E; ++c) dst[c * G::LANES] = x[c];
@@ -3212,7 +3254,7 @@ static int launch_units_io_t(const LaunchCfg& cfg, const Program* d_prog, const 
   return 0;
 }
 
-template <int LOGN, bool HAS_SHIFT, class TM = WaveTeam>
+template <int LOGN, bool HAS_SHIFT, class TM = WaveTeam, bool DD = false>
 static int launch_rows_t(const LaunchCfg& cfg, const Program* d_prog, const Operands& ops, const uint32_t* d_key_ntt,
                          const double* d_key_l2, const DevTables* T, const uint32_t* d_tw, uint32_t* d_scratch,
                          uint8_t* d_flags, uint32_t ntasks) {
@@ -3220,12 +3262,12 @@ static int launch_rows_t(const LaunchCfg& cfg, const Program* d_prog, const Oper
   constexpr int TPB = TM::kTeamsPerBlock;
   const size_t lds = TPB * team_lds_words<LOGN, TM, HAS_SHIFT>() * sizeof(uint32_t);   // per team: transposition slab + state word A
   if (lds > 48 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&row_kernel<LOGN, HAS_SHIFT, TM>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&row_kernel<LOGN, HAS_SHIFT, TM, DD>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
   const unsigned grid = grid_for(ntasks, cfg.num_cus, TPB, TM::LL == 6 ? 32 / TPB : 8);   // <= 32 team lines per CU (scratch sizing)
-  hipLaunchKernelGGL((row_kernel<LOGN, HAS_SHIFT, TM>), dim3(grid), dim3(TPB << TM::LL), lds, (hipStream_t)cfg.stream, d_prog, ops,
+  hipLaunchKernelGGL((row_kernel<LOGN, HAS_SHIFT, TM, DD>), dim3(grid), dim3(TPB << TM::LL), lds, (hipStream_t)cfg.stream, d_prog, ops,
                      d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks);
   RZK_LAUNCH_CHECK();
   return 0;
@@ -3233,11 +3275,19 @@ static int launch_rows_t(const LaunchCfg& cfg, const Program* d_prog, const Oper
 
 int launch_rows(int logn, const LaunchCfg& cfg, const Program* d_prog, uint32_t nrows, bool has_shift, const Operands& ops,
                 const uint32_t* d_key_ntt, const double* d_key_l2, const DevTables* T, const uint32_t* d_tw,
-                uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch) {
+                uint32_t* d_scratch, uint8_t* d_flags, uint64_t batch, bool has_dd) {
   if (batch == 0 || nrows == 0) return 0;
   if (batch * nrows >= (1ull << 32)) return -2;
   const uint32_t ntasks = (uint32_t)(batch * nrows);
 #define RZK_ROWS_ARGS cfg, d_prog, ops, d_key_ntt, d_key_l2, T, d_tw, d_scratch, d_flags, ntasks
+  if (has_dd && !has_shift) {   // rows whose operand transforms may come from the call's operand images (TERM_DD)
+    switch (logn) {
+      case 9: return launch_rows_t<9, false, WaveTeam, true>(RZK_ROWS_ARGS);
+      case 10: return launch_rows_t<10, false, WaveTeam, true>(RZK_ROWS_ARGS);
+      case 11: return cfg.pair_poly ? launch_rows_t<11, false, PairTeam, true>(RZK_ROWS_ARGS) : launch_rows_t<11, false, WaveTeam, true>(RZK_ROWS_ARGS);
+    }
+    return -1;
+  }
   switch (logn) {
     case 9: return has_shift ? launch_rows_t<9, true>(RZK_ROWS_ARGS) : launch_rows_t<9, false>(RZK_ROWS_ARGS);
     case 10: return has_shift ? launch_rows_t<10, true>(RZK_ROWS_ARGS) : launch_rows_t<10, false>(RZK_ROWS_ARGS);

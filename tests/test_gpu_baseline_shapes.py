@@ -249,6 +249,12 @@ def test_config5_shape_vs_oracle(torch_mod):
     dict(N=1024, shape=(2, 5, 2), V=2, env={"RZK_DKEY": 2, "RZK_SUM_D": 1}),
     dict(N=1024, shape=(4, 9, 4), V=8, env={"RZK_DKEY": 0}),
     dict(N=2048, shape=(2, 5, 2), V=3, env={"RZK_DKEY": 0}),
+    # operand images (the D rows read the transforms the a1.v_i products left): producers on the group kernel
+    # (N <= 1024), the block kernel (N = 2048), none at all (unit path: the rows fall back to their own transforms)
+    dict(N=1024, shape=(2, 5, 2), V=3, env={"RZK_DKEY": 2, "RZK_SUM_D": 1}),
+    dict(N=2048, shape=(2, 5, 2), V=3, env={"RZK_DKEY": 2, "RZK_SUM_D": 1}),
+    dict(N=512, shape=(2, 5, 2), V=2, env={"RZK_DKEY": 2, "RZK_SUM_D": 1, "RZK_ROW_GROUPS": 0, "RZK_BLOCK_MIN_LOGN": 12}),
+    dict(N=1024, shape=(4, 9, 4), V=8, env={"RZK_OIMG": 0}),
 ])
 def test_forced_kernel_paths_vs_oracle(torch_mod, cfg):
     N, (n, k, l), V = cfg["N"], cfg["shape"], cfg["V"]

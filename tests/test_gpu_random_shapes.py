@@ -39,6 +39,8 @@ KNOBS = [
     {"RZK_LIN_E": 0},       # Linear verifier in the reference's grouping (two products with g) instead of g(.)e - e' - u
     {"RZK_LIN_E": 0, "RZK_DKEY": 2},
     {"RZK_SHIFT": 0, "RZK_DKEY": 2},
+    {"RZK_DKEY": 2, "RZK_SUM_D": 1},                 # small shapes through the image paths: multipliers and operand images
+    {"RZK_DKEY": 2, "RZK_SUM_D": 1, "RZK_OIMG": 0},  # ... and without the operand images
 ]
 
 

@@ -975,8 +975,8 @@ int run_program(rzk_ctx* c, int id, uint32_t var, const std::vector<OpSpec>& spe
     else if (dp.ngroups) pi.kernel = "row_group_kernel<" + L + ", " + std::to_string(c->logn >= 11 ? 2 : RZK_GROUP_GM) + ">";
     else if (dp.d_slots) pi.kernel = "fwd_slots_kernel<" + L + "> + row_slots_kernel<" + L + ">";
     else if (row_path)
-      pi.kernel = "row_kernel<" + L + ", " + (dp.has_shift ? "true" : "false") + (pairs ? ", PairTeam" : (dp.has_dd ? ", WaveTeam" : "")) +
-                  (dp.has_dd && !dp.has_shift ? ", true>" : ">");
+      pi.kernel = "row_kernel<" + L + ", " + (dp.has_shift ? "true" : "false") + (pairs ? ", PairTeam" : ", WaveTeam") +
+                  (dp.has_dd && !dp.has_shift ? ", true>" : ", false>");
     else if (!dp.has_vec && c->unit_io && !(c->logn == 11 && dp.has_shift))
       pi.kernel = "unit_io_kernel<" + L + ", " + (dp.has_shift ? "true" : "false") + (pairs ? ", PairTeam>" : ">");
     else

@@ -3352,6 +3352,9 @@ static int launch_shift_t(const LaunchCfg& cfg, const Program* d_prog, const Ope
   // Teams of two (N = 2048): 18 KiB per 128-thread workgroup, eight workgroups = 4 waves per SIMD.
   size_t lds = (size_t)TPB * ShiftCfg<LOGN, TM>::WORDS * sizeof(uint32_t);
   if (TM::LL == 6 && LOGN >= 10 && lds < 40 * 1024) lds = 40 * 1024;   // (N = 512 keeps its 6 waves per SIMD: 4-KiB images, measured fine in round 2)
+#ifdef RZK_SHIFT_PAIR_LDS_KB   // experiment: fewer pairs per CU at N = 2048 (18 KiB = 8 pairs, 22 = 7, 26 = 6)
+  if (TM::LL == 7 && lds < (size_t)RZK_SHIFT_PAIR_LDS_KB * 1024) lds = (size_t)RZK_SHIFT_PAIR_LDS_KB * 1024;
+#endif
   if (lds > 48 * 1024) {
     hipError_t e = ops.trusted ? hipFuncSetAttribute(reinterpret_cast<const void*>(&shift_row_kernel<LOGN, true, TM>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
